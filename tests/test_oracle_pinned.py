@@ -1,0 +1,127 @@
+"""Pin the CPU oracle (oracle/xsd_oracle.c + oracle/oracle.py) against the golden vectors that
+tests/golden/make_golden.py produced by running the REFERENCE's own modules
+(models/modules/generator_rrdb.py, rrdb_blocks.py, transforms/*, data/tools.py) in the build container.
+Tolerances: fp32 conv stacks 2e-5 abs on outputs in [0,1]; grads 1e-4 relative to the tensor's max;
+transforms: bit-exact for mask/pad/upsample/linear; sqrt within 1 ulp (torch's CPU sqrt is not
+correctly rounded: 0.510507 -> 0.7144977 vs the IEEE result 0.71449775); 1e-6 for asinh/log."""
+import os
+
+import numpy as np
+import pytest
+
+import gen_common as gc
+from oracle import oracle
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+CASES = [
+    ("dn_nf8_b1", "dn"), ("sr_nf8_b1", "sr"), ("sr_nf8_b1_up2", "sr"),
+    ("dn_nf32_b4_32x32", "dn"), ("dn_nf32_b4_24x40", "dn"),
+    ("sr_nf32_b4_24x40", "sr"), ("sr_nf32_b4_17x45", "sr"), ("dn_nf32_b1_64x64", "dn"),
+]
+
+
+def load_case(name, kind):
+    z = np.load(os.path.join(G, name + ".npz"))
+    nf, blocks, nup, wseed, xseed, tseed = [int(v) for v in z["meta"][:6]]
+    xshape = tuple(int(v) for v in z["meta"][6:])
+    lb = float(z["last_bias"][0])
+    state = gc.make_state(kind, nf, blocks, wseed, num_upsample=nup, last_bias=None if np.isnan(lb) else lb)
+    x = gc.make_input(xshape, xseed)
+    s = 2 ** nup if kind == "sr" else 1
+    t = gc.make_input((xshape[0], 1, xshape[2] * s, xshape[3] * s), tseed)
+    return z, nf, blocks, nup, state, x, t
+
+
+@pytest.mark.parametrize("name,kind", CASES)
+def test_oracle_forward_backward_matches_reference(name, kind):
+    z, nf, blocks, nup, state, x, t = load_case(name, kind)
+    flat = oracle.flatten_state(state)
+    y, loss, dx, grads = oracle.l1_train(kind, nf, blocks, flat, x, t, num_upsample=nup)
+    assert np.abs(y - z["y"]).max() < 2e-5
+    assert abs(loss - float(z["loss"][0])) < 1e-6
+    dxr = z["dx"]
+    assert np.abs(dx - dxr).max() <= 1e-4 * np.abs(dxr).max() + 1e-9
+    shapes = gc.rrdb_param_shapes(kind, nf, blocks, num_upsample=nup)
+    g = oracle.unflatten(grads, shapes)
+    names = [str(n) for n in z["param_names"]]
+    assert names == list(shapes.keys())
+    for i, n in enumerate(names):
+        s_ref, a_ref = z["grad_sums"][i]
+        gi = g[n].astype(np.float64)
+        assert abs(np.abs(gi).sum() - a_ref) <= 2e-4 * a_ref + 1e-9, n
+        assert abs(gi.sum() - s_ref) <= 2e-4 * a_ref + 1e-9, n
+        if "grad." + n in z.files:
+            gr = z["grad." + n]
+            assert np.abs(g[n] - gr).max() <= 2e-4 * np.abs(gr).max() + 1e-10, n
+
+
+def test_oracle_forward_only_equals_train_forward():
+    z, nf, blocks, nup, state, x, t = load_case("sr_nf8_b1", "sr")
+    y = oracle.forward("sr", nf, blocks, oracle.flatten_state(state), x, num_upsample=nup)
+    assert np.abs(y - z["y"]).max() < 2e-5
+
+
+def test_torch_restatement_matches_reference():
+    import torch
+    z, nf, blocks, nup, state, x, t = load_case("sr_nf32_b4_17x45", "sr")
+    st = {k: torch.from_numpy(v) for k, v in state.items()}
+    y = oracle.torch_forward("sr", nf, blocks, st, torch.from_numpy(x), nup).numpy()
+    assert np.abs(y - z["y"]).max() < 1e-6
+    z, nf, blocks, nup, state, x, t = load_case("dn_nf32_b4_24x40", "dn")
+    st = {k: torch.from_numpy(v) for k, v in state.items()}
+    y = oracle.torch_forward("dn", nf, blocks, st, torch.from_numpy(x)).numpy()
+    assert np.abs(y - z["y"]).max() < 1e-6
+
+
+def test_adam_matches_torch():
+    import torch
+    rng = np.random.default_rng(5)
+    p = rng.normal(size=1000).astype(np.float32)
+    tp = torch.nn.Parameter(torch.from_numpy(p.copy()))
+    opt = torch.optim.Adam([tp], lr=1e-4, betas=(0.9, 0.999))   # models/model.py:241-245, models.toml:7-8
+    m = np.zeros_like(p); v = np.zeros_like(p)
+    for step in range(1, 6):
+        g = rng.normal(size=1000).astype(np.float32) * 0.01
+        tp.grad = torch.from_numpy(g.copy())
+        opt.step()
+        oracle.adam(p, g, m, v, step)
+        assert np.abs(p - tp.detach().numpy()).max() < 2e-7
+
+
+# ----------------------------------------------------------------------------- transforms
+def test_transforms_match_reference():
+    z = np.load(os.path.join(G, "transforms.npz"))
+    img = z["norm_in"]
+    for mode, tol in (("linear", 0.0), ("sqrt", 1.2e-7), ("asinh", 1e-6), ("log", 1e-6)):
+        for tag, mv in (("lr", 0.0022336), ("hr", 0.0005584)):
+            out = oracle.normalize(img, mv, mode)
+            assert np.abs(out - z[f"norm_{tag}_{mode}"]).max() <= tol, (mode, tag)
+            den = oracle.denormalize(z[f"denorm_in_{mode}"], mv, mode)
+            ref = z[f"denorm_{tag}_{mode}"]
+            assert np.abs(den - ref).max() <= tol * mv + (0 if tol == 0 else 1e-9), (mode, tag)
+    assert np.array_equal(oracle.normalize(z["norm_auto_in"], 0.0, "sqrt"), z["norm_auto_sqrt"])
+    assert np.array_equal(oracle.image_upsample(z["up_in3"], 2), z["up_out3"])
+    assert np.array_equal(oracle.image_upsample(z["up_in4"], 2), z["up_out4"])
+    for key in [k for k in z.files if k.startswith("pad_in_")]:
+        _, _, hw, res = key.split("_")
+        a = z[key].astype(np.float32)
+        r = oracle.reshape_img_to_res(a, int(res))
+        assert np.array_equal(r, z[key.replace("pad_in_", "pad_out_")].astype(np.float32)), key
+
+
+@pytest.mark.slow
+def test_example_data_pipeline_and_dn_forward():
+    """Config 1: real 20ks tile -> mask -> pad -> sqrt-normalize -> DN forward; PSNR within 0.01 dB of the reference."""
+    z = np.load(os.path.join(G, "example_data.npz"))
+    m1 = np.unpackbits(z["mask1x_bits"])[: int(np.prod(z["mask1x_shape"]))].reshape(z["mask1x_shape"])
+    assert m1.sum() == 132399   # SURVEY.md section 0 (mask population)
+    state = gc.make_state("dn", 32, 4, 1234)
+    flat = oracle.flatten_state(state)
+    i = 0
+    x = oracle.normalize(oracle.mask_pad(z[f"dn_counts20_{i}"], m1, 416), 0.0022336, "sqrt")[None]
+    assert abs(float(x.astype(np.float64).sum()) - float(z[f"dn_x_sum_{i}"][0])) < 1e-6
+    t = oracle.normalize(oracle.mask_pad(z[f"dn_counts50_{i}"], m1, 416), 0.0022336, "sqrt")[None]
+    y = oracle.forward("dn", 32, 4, flat, x)[0, 0]
+    assert np.abs(y[::5, ::5] - z[f"dn_y_sub_{i}"]).max() < 5e-5
+    assert abs(gc.psnr(y, t[0, 0]) - float(z[f"dn_psnr_{i}"][0])) < 0.01
