@@ -1,0 +1,120 @@
+/*
+ * xsd.h -- C ABI of the MI355X-native RRDB-generator engine (libxsd_hip.so).
+ *
+ * Drop-in boundary for the hot path of SamSweere/xmm-superres-denoise.  All pointers named
+ * "dev" are device (HBM) pointers owned by the caller; the engine borrows them for the duration of a call and
+ * launches asynchronously on the given hipStream_t (passed as void*; NULL = the null stream).  Every entry point
+ * returns 0 on success or a negative xsd_status; xsd_last_error() returns a thread-local message.  No C++ types,
+ * no torch types, never throws across the ABI.  One engine per process/GPU; calls on one engine are stream-ordered,
+ * not thread-safe.
+ *
+ * Parameter vector layout ("flat params"): fp32, the reference's state_dict order, each tensor OIHW:
+ *   conv_first.{weight,bias}, rrdb.{i}.RDB{r}.conv{c}.{weight,bias} (i<blocks, r=1..3, c=1..5), trunk_conv.*,
+ *   conv_last.*, and for SR: upsampling.{3u}.* (u<num_upsample), HRconv.*
+ *   (xmm_superres_denoise/models/modules/generator_rrdb.py:10-64,73-101; rrdb_blocks.py:23-32,60-64).
+ * Images are NCHW with C = 1, i.e. plain [B][H][W] fp32.
+ */
+#ifndef XSD_H
+#define XSD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xsd_engine xsd_engine;
+
+enum xsd_status {
+    XSD_OK = 0,
+    XSD_ERR_ARG = -1,     /* bad argument / unsupported configuration */
+    XSD_ERR_HIP = -2,     /* a HIP runtime call failed */
+    XSD_ERR_STATE = -3,   /* call sequence error (e.g. backward without a saved forward) */
+    XSD_ERR_NOMEM = -4
+};
+
+enum xsd_kind { XSD_KIND_DN = 0, XSD_KIND_SR = 1 };
+
+/* Mirrors the constructor arguments of GeneratorRRDB_DN / GeneratorRRDB_SR
+ * (generator_rrdb.py:114-121 / :73-81) as mapped from RrdbCfg by Model.configure_model (models/model.py:157-186). */
+typedef struct xsd_config {
+    int32_t kind;          /* xsd_kind */
+    int32_t in_channels;   /* must be 1 */
+    int32_t out_channels;  /* must be 1 */
+    int32_t num_filters;   /* must be 32 (models.toml: filters = 32) */
+    int32_t num_res_blocks;/* >= 1 (models.toml: residual_blocks = 4) */
+    int32_t num_upsample;  /* SR only: (hr_res/lr_res)/2, 1 or 2 */
+    int32_t memory_efficient; /* accepted for API parity (rrdb_blocks.py:39-47 recompute policy); numerics identical */
+    int32_t reserved;
+} xsd_config;
+
+const char* xsd_last_error(void);
+const char* xsd_version(void);
+
+/* replaces GeneratorRRDB_*.__init__ (engine state only; weights stay in the caller's flat buffer) */
+int xsd_create(const xsd_config* cfg, xsd_engine** out);
+void xsd_destroy(xsd_engine* e);
+int64_t xsd_param_count(const xsd_engine* e);
+
+/* Repack the caller's flat OIHW parameters into MFMA fragment-order panels (forward + transposed/flipped for the
+ * input-gradient).  Must be called after every parameter update and before forward.  Replaces nothing in the
+ * reference (torch reads OIHW directly); it is the engine's weight-layout step. */
+int xsd_pack_weights(xsd_engine* e, const float* dev_params, void* stream);
+
+/* replaces Model.forward = clamp(GeneratorRRDB_*.forward(x), 0, 1) (models/model.py:48-49;
+ * generator_rrdb.py:66-69,103-110,130-137).  x: [B][H][W]; y: [B][sH][sW], s = 2^num_upsample (SR) or 1 (DN).
+ * save_for_backward != 0 keeps every activation needed by xsd_backward (about 7.7 KB per LR pixel). */
+int xsd_forward(xsd_engine* e, const float* dev_x, float* dev_y, int B, int H, int W, int save_for_backward, void* stream);
+
+/* replaces torch autograd through the module for the last xsd_forward(save_for_backward=1):
+ * dy: gradient wrt the (clamped) output y; dx_or_null: gradient wrt x; dev_grads: flat gradient vector in the flat-params
+ * layout (overwritten, not accumulated). */
+int xsd_backward(xsd_engine* e, const float* dev_dy, float* dev_dx_or_null, float* dev_grads, void* stream);
+
+/* Data-parallel overlap support: the backward pass split into num_res_blocks + 2 stages, executed in order
+ * stage 0 (output head + trunk_conv), stages 1..blocks (RRDB blocks-1 .. 0), stage blocks+1 (conv_first).
+ * After stage s returns, the gradient ranges reported by xsd_grad_range(stage) are final on the stream, so the caller
+ * can start their all-reduce on a side stream while later stages run. */
+int xsd_backward_num_stages(const xsd_engine* e);
+int xsd_backward_stage(xsd_engine* e, int stage, const float* dev_dy, float* dev_dx_or_null, float* dev_grads, void* stream);
+int xsd_grad_range(const xsd_engine* e, int stage, int range_idx, int64_t* offset, int64_t* count); /* returns number of ranges */
+
+/* mean-L1 loss (torchmetrics MeanAbsoluteError / F.l1_loss; utils/loss_functions.py:16): writes *dev_loss (float) and,
+ * if dev_dy != NULL, d loss / d y = sign(y - t) / n. */
+int xsd_l1_loss(xsd_engine* e, const float* dev_y, const float* dev_target, float* dev_dy_or_null, float* dev_loss,
+                int64_t n, void* stream);
+
+/* torch.optim.Adam(lr, betas, eps=1e-8) single fused step over flat buffers (models/model.py:241-245).
+ * step is 1-based; grad_scale multiplies the gradient on read (1/world_size for data-parallel mean). */
+int xsd_adam_step(xsd_engine* e, float* dev_params, const float* dev_grads, float* dev_m, float* dev_v, int64_t n,
+                  int step, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* Input pipeline: counts (int32 or fp32, [B][Hin][Win]) * detector mask (uint8 {0,1} [Hin][Win] or NULL)
+ * -> centred zero pad / crop to [B][res][res] -> optional Normalize.normalize_image(max_val, stretch)
+ * (data/dataset.py:41-47; data/tools.py:103-126; transforms/normalize.py:66-82).
+ * stretch: 0 linear, 1 sqrt, 2 asinh, 3 log.  do_normalize = 0 returns the masked, padded counts (bit-exact). */
+int xsd_mask_pad_normalize(const void* dev_counts, int counts_is_int32, const uint8_t* dev_mask_or_null, float* dev_out,
+                           int B, int Hin, int Win, int res, int do_normalize, float max_val, int stretch, void* stream);
+/* Normalize.normalize_image (inverse = 0) / denormalize_image (inverse = 1), max_val > 0 (transforms/normalize.py:66-92) */
+int xsd_normalize(const float* dev_in, float* dev_out, int64_t n, float max_val, int stretch, int inverse, void* stream);
+/* ImageUpsample: nearest x scale then / scale^2 (transforms/imageupsample.py:10-26); in [N][H][W] */
+int xsd_image_upsample(const float* dev_in, float* dev_out, int N, int H, int W, int scale, void* stream);
+
+/* ---- measurement / test hooks ------------------------------------------------------------------------------- */
+/* Per-kernel-class HIP-event timing of the MFMA kernels launched by this engine (bench.py roofline block).
+ * class 0 = conv3x3_mfma (forward + input-gradient), 1 = wgrad_mfma.  enable resets the counters. */
+int xsd_profile_enable(xsd_engine* e, int enable);
+int xsd_profile_read(xsd_engine* e, int klass, double* total_ms, int64_t* launches, double* total_flop, double* total_bytes);
+
+/* Single-layer entry points used by the kernel-level parity tests (one 3x3 conv over NHWC 32-channel planes).
+ * dev_in: [n_in] plane pointers on the host (each plane [B][H][W][32]); w_oihw: device OIHW [32*n_out][32*n_in][3][3]. */
+int xsd_test_conv3x3(xsd_engine* e, const float* const* host_in_planes, int n_in, const float* dev_w_oihw, const float* dev_bias,
+                     float* const* host_out_planes, int n_out, float slope, int B, int H, int W, void* stream);
+int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* host_in_planes, int n_in, const float* dev_w_oihw,
+                         const float* dev_g_plane, float* const* host_dx_planes, float* dev_dw_oihw, float* dev_db,
+                         int B, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XSD_H */

@@ -1,0 +1,94 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/xsd.h declares,
+the Python surface mirrors the reference's names, and the product path fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from xmm_superres_denoise.engine import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    hdr = open(os.path.join(ROOT, "include", "xsd.h")).read()
+    declared = set(re.findall(r"\b(xsd_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
+    for s in declared:
+        assert hasattr(L, s), s
+    L.xsd_version.restype = ctypes.c_char_p
+    assert b"gfx950" in L.xsd_version()
+
+
+def test_python_surface_matches_reference_names():
+    import xmm_superres_denoise.models as M
+    import xmm_superres_denoise.transforms as T
+    from xmm_superres_denoise.config.config import ModelCfg, OptimizerCfg, RrdbCfg, model_cfg
+    for n in ("Model", "GeneratorRRDB_DN", "GeneratorRRDB_SR"):
+        assert hasattr(M, n)
+    for n in ("Crop", "ImageUpsample", "Normalize"):
+        assert hasattr(T, n)
+    import inspect
+    sig = inspect.signature(M.GeneratorRRDB_SR.__init__)
+    assert list(sig.parameters)[1:] == ["in_channels", "out_channels", "num_filters", "num_res_blocks", "num_upsample", "memory_efficient"]
+    assert sig.parameters["num_upsample"].default == 2
+    sig = inspect.signature(M.GeneratorRRDB_DN.__init__)
+    assert list(sig.parameters)[1:] == ["in_channels", "out_channels", "num_filters", "num_res_blocks", "memory_efficient"]
+    cfg = model_cfg("esr_gen", batch_size=4)
+    assert isinstance(cfg, ModelCfg) and isinstance(cfg.model, RrdbCfg) and isinstance(cfg.optimizer, OptimizerCfg)
+    m = M.Model(cfg, (416, 416), (832, 832), None, None, None, None, None)
+    m.configure_model()
+    assert isinstance(m.model, M.GeneratorRRDB_SR) and m.model.num_upsample == 1
+    with pytest.raises(ValueError):
+        M.Model(cfg, (416, 416), (1248, 1248), None, None, None, None, None).configure_model()
+    opt = m.configure_optimizers()
+    assert isinstance(opt, torch.optim.Adam) and opt.defaults["lr"] == 1e-4 and opt.defaults["betas"] == (0.9, 0.999)
+
+
+def test_state_dict_keys_and_default_init_match_reference():
+    import numpy as np
+    import xmm_superres_denoise.models as M
+    z = np.load(os.path.join(ROOT, "tests", "golden", "init_parity.npz"))
+    for kind in ("dn", "sr"):
+        torch.manual_seed(0)
+        m = M.GeneratorRRDB_DN(1, 1, 32, 4) if kind == "dn" else M.GeneratorRRDB_SR(1, 1, 32, 4, num_upsample=1)
+        sd = m.state_dict()
+        assert list(sd.keys()) == [str(n) for n in z[kind + "_names"]]
+        assert sum(p.numel() for p in m.parameters()) == int(z[kind + "_nparams"][0])
+        st = z[kind + "_stats"]
+        for i, k in enumerate(sd.keys()):
+            v = sd[k].double().flatten()
+            assert abs(v.sum().item() - st[i, 0]) < 1e-9 and abs(v.abs().sum().item() - st[i, 1]) < 1e-9, k
+        flat = m.flatten_parameters()
+        assert flat.numel() == int(z[kind + "_nparams"][0])
+        assert m.conv_first.weight.data_ptr() == flat.data_ptr()
+        # a round trip through state_dict keeps the flat aliasing
+        m.load_state_dict({k: v.clone() for k, v in sd.items()})
+        assert m.conv_first.weight.data_ptr() == flat.data_ptr()
+
+
+def test_product_path_fails_loudly_on_cpu():
+    import xmm_superres_denoise.models as M
+    from xmm_superres_denoise.engine import XsdError
+    from xmm_superres_denoise.transforms import ImageUpsample, Normalize
+    m = M.GeneratorRRDB_DN(1, 1, 32, 1)
+    with pytest.raises(XsdError):
+        m(torch.zeros(1, 1, 8, 8))
+    with pytest.raises(XsdError):
+        Normalize(1.0, 1.0, "sqrt").normalize_lr_image(torch.zeros(1, 4, 4))
+    with pytest.raises(XsdError):
+        ImageUpsample(2)(torch.zeros(1, 4, 4))
+
+
+def test_no_product_import_of_oracle():
+    """The product package must never import, call or link anything under oracle/."""
+    pkg = os.path.join(ROOT, "xmm-superres-denoise_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "oracle" not in txt.lower() or f == "README.md", os.path.join(dp, f)

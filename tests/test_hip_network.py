@@ -1,0 +1,155 @@
+"""GPU parity of the whole generators (forward, L1 backward) against (1) the golden vectors generated from the
+reference modules and (2) the CPU oracle on fresh seeded inputs, through the drop-in nn.Module API.
+north_star tolerance: 1e-3 relative fp32; measured errors are ~1e-6..1e-5, the asserts use 1e-4."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gen_common as gc
+from oracle import oracle
+from util_hip import G, build_module, load_case
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("dn_nf32_b4_32x32", "dn"), ("dn_nf32_b4_24x40", "dn"), ("sr_nf32_b4_24x40", "sr"),
+         ("sr_nf32_b4_17x45", "sr"), ("dn_nf32_b1_64x64", "dn")]
+
+
+def _relmax(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.mark.parametrize("name,kind", CASES)
+def test_golden_forward_backward(name, kind):
+    z, nf, blocks, nup, state, x, t = load_case(name, kind)
+    m = build_module(kind, blocks, nup, state)
+    xd = torch.from_numpy(x).cuda().requires_grad_(True)
+    y = m(xd)
+    assert np.abs(y.detach().cpu().numpy() - z["y"]).max() < 1e-4
+    loss = torch.nn.functional.l1_loss(y, torch.from_numpy(t).cuda())
+    assert abs(loss.item() - float(z["loss"][0])) < 1e-5
+    loss.backward()
+    assert _relmax(xd.grad.cpu().numpy(), z["dx"]) < 1e-4
+    names = [str(n) for n in z["param_names"]]
+    params = dict(m.named_parameters())
+    assert list(params.keys()) == names
+    for i, n in enumerate(names):
+        g = params[n].grad.cpu().numpy().astype(np.float64)
+        s_ref, a_ref = z["grad_sums"][i]
+        assert abs(np.abs(g).sum() - a_ref) <= 2e-4 * a_ref + 1e-9, n
+        assert abs(g.sum() - s_ref) <= 2e-4 * a_ref + 1e-9, n
+        if "grad." + n in z.files:
+            assert _relmax(g, z["grad." + n]) < 2e-4, n
+
+
+def test_forward_no_grad_matches_train_forward_and_reuses_planes():
+    z, nf, blocks, nup, state, x, t = load_case("sr_nf32_b4_24x40", "sr")
+    m = build_module("sr", blocks, nup, state)
+    with torch.no_grad():
+        y = m(torch.from_numpy(x).cuda())
+    assert np.abs(y.cpu().numpy() - z["y"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("kind,shape", [("dn", (3, 1, 41, 67)), ("sr", (2, 1, 33, 35))])
+def test_fresh_inputs_vs_oracle(kind, shape):
+    state = gc.make_state(kind, 32, 2, 900, num_upsample=1, last_bias=0.3 if kind == "sr" else None)
+    x = gc.make_input(shape, 901)
+    s = 2 if kind == "sr" else 1
+    t = gc.make_input((shape[0], 1, shape[2] * s, shape[3] * s), 902)
+    yo, lo, dxo, go = oracle.l1_train(kind, 32, 2, oracle.flatten_state(state), x, t, num_upsample=1)
+    m = build_module(kind, 2, 1, state)
+    eng = m._get_engine(torch.device("cuda", 0))
+    eng.pack(m.flat_parameters())
+    xd = torch.from_numpy(x).cuda()
+    y = eng.forward(xd, save_for_backward=True)
+    loss, dy = eng.l1_loss(y, torch.from_numpy(t).cuda())
+    grads = torch.empty_like(m.flat_parameters())
+    dx = eng.backward(dy, grads, need_dx=True)
+    assert np.abs(y.cpu().numpy() - yo).max() < 1e-4
+    assert abs(loss.item() - lo) < 1e-5
+    assert _relmax(dx.cpu().numpy(), dxo) < 1e-4
+    g = grads.cpu().numpy()
+    shapes = gc.rrdb_param_shapes(kind, 32, 2, num_upsample=1)
+    off = 0
+    for n, shp in shapes.items():
+        k = int(np.prod(shp))
+        assert _relmax(g[off:off + k], go[off:off + k]) < 2e-4, n
+        off += k
+
+
+def test_staged_backward_equals_monolithic():
+    z, nf, blocks, nup, state, x, t = load_case("dn_nf32_b4_24x40", "dn")
+    m = build_module("dn", blocks, nup, state)
+    eng = m._get_engine(torch.device("cuda", 0))
+    eng.pack(m.flat_parameters())
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    y = eng.forward(xd, save_for_backward=True)
+    _, dy = eng.l1_loss(y, td)
+    g1 = torch.zeros_like(m.flat_parameters())
+    eng.backward(dy, g1)
+    g2 = torch.full_like(g1, float("nan"))
+    covered = 0
+    for st in range(eng.num_stages):
+        eng.backward_stage(st, dy, g2)
+        off, cnt = eng.grad_range(st)
+        covered += cnt
+        torch.cuda.synchronize()
+        assert torch.isfinite(g2[off:off + cnt]).all()
+    assert covered == g1.numel()
+    assert torch.equal(g1, g2)
+
+
+def test_train_step_adam_matches_oracle():
+    """3 optimisation steps (L1 + Adam lr 1e-4) from the same weights: engine vs oracle."""
+    kind, blocks = "dn", 1
+    state = gc.make_state(kind, 32, blocks, 77)
+    x = gc.make_input((2, 1, 24, 40), 78)
+    t = gc.make_input((2, 1, 24, 40), 79)
+    p = oracle.flatten_state(state).copy()
+    mo, vo = np.zeros_like(p), np.zeros_like(p)
+    m = build_module(kind, blocks, 1, state)
+    eng = m._get_engine(torch.device("cuda", 0))
+    flat = m.flat_parameters()
+    md, vd = torch.zeros_like(flat), torch.zeros_like(flat)
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    grads = torch.empty_like(flat)
+    for step in range(1, 4):
+        _, lo, _, go = oracle.l1_train(kind, 32, blocks, p, x, t)
+        oracle.adam(p, go, mo, vo, step)
+        eng.pack(flat)
+        y = eng.forward(xd, save_for_backward=True)
+        loss, dy = eng.l1_loss(y, td)
+        eng.backward(dy, grads)
+        eng.adam_step(flat, grads, md, vd, step)
+        assert abs(loss.item() - lo) < 1e-5
+    # Adam's first steps move each weight by ~lr regardless of gradient scale: compare the update direction
+    assert np.abs(flat.cpu().numpy() - p).max() < 2.5e-4
+    d_eng = flat.cpu().numpy() - oracle.flatten_state(state)
+    d_ora = p - oracle.flatten_state(state)
+    assert np.mean(np.sign(d_eng) == np.sign(d_ora)) > 0.98
+
+
+def test_example_data_psnr_parity():
+    """PSNR(engine) within 0.01 dB of PSNR(reference) on example_data tiles with identical seeded weights."""
+    from xmm_superres_denoise.data.tools import load_and_prepare
+    z = np.load(os.path.join(G, "example_data.npz"))
+    m1 = np.unpackbits(z["mask1x_bits"])[: int(np.prod(z["mask1x_shape"]))].reshape(z["mask1x_shape"])
+    m2 = np.unpackbits(z["mask2x_bits"])[: int(np.prod(z["mask2x_shape"]))].reshape(z["mask2x_shape"])
+    m1d, m2d = torch.from_numpy(m1).cuda(), torch.from_numpy(m2).cuda()
+    dn = build_module("dn", 4, 1, gc.make_state("dn", 32, 4, 1234))
+    sr = build_module("sr", 4, 1, gc.make_state("sr", 32, 4, 4321, last_bias=0.05))
+    with torch.no_grad():
+        for i in range(2):
+            x = load_and_prepare(torch.from_numpy(z[f"dn_counts20_{i}"]).cuda()[None], m1d, 416, 0.0022336, "sqrt")
+            t = load_and_prepare(torch.from_numpy(z[f"dn_counts50_{i}"]).cuda()[None], m1d, 416, 0.0022336, "sqrt")
+            assert abs(float(x.double().sum()) - float(z[f"dn_x_sum_{i}"][0])) < 1e-3
+            y = dn(x)[0, 0].cpu().numpy()
+            assert np.abs(y[::5, ::5] - z[f"dn_y_sub_{i}"]).max() < 1e-4
+            assert abs(gc.psnr(y, t[0, 0].cpu().numpy()) - float(z[f"dn_psnr_{i}"][0])) < 0.01
+            x = load_and_prepare(torch.from_numpy(z[f"sr_counts_lr_{i}"]).cuda()[None], m1d, 416, 0.0022336, "sqrt")
+            t = load_and_prepare(torch.from_numpy(z[f"sr_counts_hr_{i}"]).cuda()[None], m2d, 832, 0.0005584, "sqrt")
+            y = sr(x)[0, 0].cpu().numpy()
+            assert np.abs(y[::9, ::9] - z[f"sr_y_sub_{i}"]).max() < 1e-4
+            assert abs(gc.psnr(y, t[0, 0].cpu().numpy()) - float(z[f"sr_psnr_{i}"][0])) < 0.01

@@ -1,0 +1,49 @@
+"""Helpers shared by the GPU parity tests (not a test module)."""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+import gen_common as gc
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load_case(name, kind):
+    z = np.load(os.path.join(G, name + ".npz"))
+    nf, blocks, nup, wseed, xseed, tseed = [int(v) for v in z["meta"][:6]]
+    xshape = tuple(int(v) for v in z["meta"][6:])
+    lb = float(z["last_bias"][0])
+    state = gc.make_state(kind, nf, blocks, wseed, num_upsample=nup, last_bias=None if np.isnan(lb) else lb)
+    x = gc.make_input(xshape, xseed)
+    s = 2 ** nup if kind == "sr" else 1
+    t = gc.make_input((xshape[0], 1, xshape[2] * s, xshape[3] * s), tseed)
+    return z, nf, blocks, nup, state, x, t
+
+
+def build_module(kind, blocks, nup, state, device="cuda"):
+    from xmm_superres_denoise.models import GeneratorRRDB_DN, GeneratorRRDB_SR
+    m = GeneratorRRDB_DN(1, 1, 32, blocks) if kind == "dn" else GeneratorRRDB_SR(1, 1, 32, blocks, num_upsample=nup)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
+    return m.to(device)
+
+
+def nchw_to_planes(a: np.ndarray):
+    """[B,C,H,W] -> list of C/32 contiguous NHWC planes [B,H,W,32] (torch cuda)"""
+    B, C, H, W = a.shape
+    out = []
+    for k in range(C // 32):
+        out.append(torch.from_numpy(np.ascontiguousarray(a[:, 32 * k:32 * k + 32].transpose(0, 2, 3, 1))).cuda())
+    return out
+
+
+def planes_to_nchw(planes):
+    return np.concatenate([p.cpu().numpy().transpose(0, 3, 1, 2) for p in planes], axis=1)
+
+
+def ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr

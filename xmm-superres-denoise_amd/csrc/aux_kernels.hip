@@ -1,0 +1,442 @@
+// aux_kernels.hip -- the HBM-bound kernels around the MFMA convs: edge layers (Cin=1 / Cout=1), loss, Adam,
+// weight repack, and the input transforms (detector mask, centred pad, Normalize, ImageUpsample).
+// Each kernel cites the reference code it replaces.
+#include "xsd_kernels.h"
+#include "xsd_aux.h"
+
+namespace xsd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------------
+// 1 -> 32 conv (conv_first forward, generator_rrdb.py:31-37,67; also the input-gradient of conv_last, :48-54).
+// Thread = (pixel, 4-channel quad): 8 consecutive lanes write one pixel's 128 B, a wave writes 1 KiB contiguous.
+// Algorithmic bytes/px: 4 read + 128 written.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams P)
+{
+    __shared__ float wl[9 * 32 + 32];
+    for (int i = threadIdx.x; i < 9 * 32; i += 256) wl[i] = P.w[i];
+    if (threadIdx.x < 32) wl[288 + threadIdx.x] = P.bias ? P.bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    const long long npix = (long long)P.B * P.H * P.W;
+    const long long total = npix * 8;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const long long pix = g >> 3;
+        const int q = (int)(g & 7);
+        const int x = (int)(pix % P.W);
+        const long long r = pix / P.W;
+        const int y = (int)(r % P.H);
+        const float* sb = P.s + (r - y) * P.W; // start of image b
+        f32x4 v = *reinterpret_cast<const f32x4*>(&wl[288 + q * 4]);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
+                const float sv = sb[(long long)yy * P.W + xx];
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wl[tap * 32 + q * 4]);
+                v += sv * w4;
+            }
+        }
+        if (P.mask) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(P.mask + pix * 32 + q * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : v[i] * P.mslope;
+        }
+        *reinterpret_cast<f32x4*>(P.out + pix * 32 + q * 4) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 32 -> 1 conv (conv_last forward + DN skip + clamp, generator_rrdb.py:107-108,132-135 and model.py:49; also the
+// input-gradient of conv_first).  8 lanes per pixel, each 4 channels x 9 taps, xor-shuffle reduction over the 8 lanes.
+// Algorithmic bytes/px: 128 read (+4 skip) + 4..8 written.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeReduceParams P)
+{
+    __shared__ float wl[9 * 32];
+    for (int i = threadIdx.x; i < 9 * 32; i += 256) wl[i] = P.w[i];
+    __syncthreads();
+    const float bias = P.bias ? P.bias[0] : 0.f;
+    const long long npix = (long long)P.B * P.H * P.W;
+    const long long total = (npix * 8 + 255) / 256 * 256; // keep whole waves alive for the shuffles
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const long long pix = g >> 3;
+        const int q = (int)(g & 7);
+        float acc = 0.f;
+        if (pix < npix) {
+            const int x = (int)(pix % P.W);
+            const long long r = pix / P.W;
+            const int y = (int)(r % P.H);
+            const float* fb = P.f + (r - y) * P.W * 32;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
+                    const f32x4 fv = *reinterpret_cast<const f32x4*>(fb + ((long long)yy * P.W + xx) * 32 + q * 4);
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wl[tap * 32 + q * 4]);
+                    acc += fv[0] * w4[0] + fv[1] * w4[1] + fv[2] * w4[2] + fv[3] * w4[3];
+                }
+            }
+        }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        acc += __shfl_xor(acc, 4);
+        if (q == 0 && pix < npix) {
+            float v = acc + bias;
+            if (P.skip) v += P.skip[pix];
+            if (P.addto) v += P.addto[pix];
+            if (P.pre) P.pre[pix] = v;
+            if (P.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+            P.y[pix] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Edge weight gradients: out[tap][c] = sum_p f[p][c] * s[p+tap];  bsum[c] = sum_p f[p][c];  ssum = sum_p s[p].
+//  conv_first: f = d(fea), s = x          -> dW[c][0][tap] = out[tap][c],   db[c] = bsum[c]
+//  conv_last : f = trunk features, s = dy -> dW[0][c][tap] = out[8-tap][c], db[0] = ssum
+// Deterministic two-stage reduction (per-block partials, then edge_wgrad_final_kernel).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_wgrad_kernel(const EdgeWgradParams P)
+{
+    __shared__ float red[256 * 4];
+    const long long npix = (long long)P.B * P.H * P.W;
+    const int q = threadIdx.x & 7;
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+    float ss = 0.f;
+    for (long long pix = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3; pix < npix; pix += (long long)gridDim.x * 32) {
+        const int x = (int)(pix % P.W);
+        const long long r = pix / P.W;
+        const int y = (int)(r % P.H);
+        const float* sb = P.s + (r - y) * P.W;
+        const f32x4 fv = *reinterpret_cast<const f32x4*>(P.f + pix * 32 + q * 4);
+        bs += fv;
+        if (q == 0) ss += sb[(long long)y * P.W + x];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) acc[tap] += fv * sb[(long long)yy * P.W + xx];
+        }
+    }
+    float* outp = P.partial + (long long)blockIdx.x * (9 * 32 + 32 + 1);
+    // reduce over the 32 threads of the block that share q
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+        const f32x4 v = t < 9 ? acc[t] : bs;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[threadIdx.x * 4 + i] = v[i];
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const int qq = threadIdx.x >> 2, i = threadIdx.x & 3;
+            float s = 0.f;
+            for (int k = 0; k < 32; ++k) s += red[(k * 8 + qq) * 4 + i];
+            outp[t * 32 + threadIdx.x] = s;
+        }
+    }
+    __syncthreads();
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int k = 0; k < 256; ++k) s += red[k];
+        outp[320] = s;
+    }
+}
+
+__global__ void edge_wgrad_final_kernel(const float* partial, int nblocks, int mode, float* dw, float* db)
+{
+    const int e = threadIdx.x + blockIdx.x * blockDim.x;
+    if (e >= 321) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)partial[(long long)b * 321 + e];
+    if (mode == 0) { // conv_first: dW[c][0][tap], db[c]
+        if (e < 288) dw[(e & 31) * 9 + (e >> 5)] = (float)s;
+        else if (e < 320) db[e - 288] = (float)s;
+    } else {         // conv_last: dW[0][c][8-tap], db[0] = ssum
+        if (e < 288) dw[(e & 31) * 9 + (8 - (e >> 5))] = (float)s;
+        else if (e == 320) db[0] = (float)s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Output-side elementwise: clamp backward (torch.clamp passes the gradient iff 0 <= v <= 1; applied for both the
+// generator's clamp and Model.forward's, generator_rrdb.py:108,135 + model.py:49) and the mean-L1 loss
+// (torchmetrics MeanAbsoluteError / F.l1_loss, utils/loss_functions.py:16).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void clamp_bwd_kernel(const float* pre, const float* dy, float* dpre, long long n)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = pre[i];
+        dpre[i] = (v >= 0.f && v <= 1.f) ? dy[i] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float* y, const float* t, float* dy, double* partial,
+                                                      long long n, float inv_n)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float d = y[i] - t[i];
+        s += (double)fabsf(d);
+        if (dy) dy[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void l1_loss_final_kernel(const double* partial, int nblocks, float* loss, double inv_n)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += partial[b];
+        *loss = (float)(s * inv_n);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// torch.optim.Adam single step (model.py:241-245; lr/betas from res/configs/models.toml:7-8), fused over the flat
+// parameter buffer.  gscale folds the data-parallel 1/world_size mean into the read of the gradient.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr_over_bc1, float inv_sqrt_bc2,
+                            float b1, float b2, float eps, float gscale)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] = p[i] - lr_over_bc1 * (mi / denom);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight repack: OIHW (state-dict layout) -> MFMA fragment-order panels.
+//  fwd panel [n][s][tap][j][h][co][t]     = W[oc(n,co)][32s + 16h+4j+t][tap]
+//  bwd panel [s][n][tap'][j][h][ci][t]    = W[oc(n,16h+4j+t)][32s + ci][8-tap']     (transposed + flipped: dgrad)
+//  oc(n,c) = 32n + c, or 4c + n for the pixel-shuffle conv (so that chunk n = sub-pixel (i,j), generator_rrdb.py:95-97)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* params, const PackDesc* descs, float* fwd, float* bwd)
+{
+    const PackDesc d = descs[blockIdx.y];
+    const int ns = d.cin / 32, nn = d.cout / 32;
+    const long long total = (long long)ns * nn * PANEL_FLOATS;
+    const float* W = params + d.src_w;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        int r = (int)(e % PANEL_FLOATS);
+        const int panel = (int)(e / PANEL_FLOATS);
+        const int t = r & 3; r >>= 2;
+        const int c = r & 31; r >>= 5;
+        const int h = r & 1; r >>= 1;
+        const int j = r & 3; r >>= 2;
+        const int tap = r;
+        const int k = 16 * h + 4 * j + t;
+        { // forward: panel = n*ns + s
+            const int n = panel / ns, s = panel % ns;
+            const int oc = d.shuffle ? (4 * c + n) : (32 * n + c);
+            fwd[d.dst_fwd + e] = W[((long long)oc * d.cin + 32 * s + k) * 9 + tap];
+        }
+        { // dgrad: panel = s*nn + n
+            const int s = panel / nn, n = panel % nn;
+            const int oc = d.shuffle ? (4 * k + n) : (32 * n + k);
+            bwd[d.dst_bwd + e] = W[((long long)oc * d.cin + 32 * s + c) * 9 + (8 - tap)];
+        }
+    }
+}
+
+// edge-layer weights: conv_first W[c][0][tap] -> [tap][c] (forward) ; conv_last W[0][c][tap] -> [tap][c] (forward)
+// and the flipped forms used by their input-gradients.
+__global__ void pack_edge_kernel(const float* w_first, const float* w_last, float* first_fwd, float* first_bwd,
+                                 float* last_fwd, float* last_bwd)
+{
+    const int e = threadIdx.x + blockIdx.x * blockDim.x;
+    if (e >= 288) return;
+    const int tap = e >> 5, c = e & 31;
+    first_fwd[e] = w_first[c * 9 + tap];       // out[p][c] += x[p+tap] * W[c][0][tap]
+    first_bwd[e] = w_first[c * 9 + (8 - tap)]; // dx[p] += sum_c g[p+tap'][c] * W[c][0][8-tap']
+    last_fwd[e] = w_last[c * 9 + tap];         // y[p] += f[p+tap][c] * W[0][c][tap]
+    last_bwd[e] = w_last[c * 9 + (8 - tap)];   // dT[p][c] += dy[p+tap'] * W[0][c][8-tap']
+}
+
+// bias of the pixel-shuffle conv in chunk order: out[n*32 + c] = b[4c + n]
+__global__ void pack_shuffle_bias_kernel(const float* b, float* out)
+{
+    const int e = threadIdx.x;
+    if (e < 128) out[e] = b[4 * (e & 31) + (e >> 5)];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Input transforms
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float stretch_fwd(float v, int mode)
+{
+    switch (mode) {
+    case 1: return sqrtf(v);                                        // torch.sqrt     (normalize.py:56-57)
+    case 2: return asinhf(v / 0.02f) / asinhf(1.0f / 0.02f);        // _asinh         (normalize.py:4-11)
+    case 3: return logf(1000.f * v + 1.f) / logf(1000.f);           // _log           (normalize.py:23-26)
+    default: return v;
+    }
+}
+__device__ __forceinline__ float stretch_inv(float v, int mode)
+{
+    switch (mode) {
+    case 1: return v * v;
+    case 2: return 0.02f * sinhf(v * asinhf(1.0f / 0.02f));         // _asinh_inv     (normalize.py:14-20)
+    case 3: return (powf(1000.f, v) - 1.f) / 1000.f;                // _log_inv       (normalize.py:29-32)
+    default: return v;
+    }
+}
+
+// counts (int32 or float32) [B][Hin][Win] (* mask uint8 [Hin][Win]) -> centred zero pad/crop -> [B][res][res]
+// -> optional Normalize.  Mask multiply by exactly 0/1 is a select, so the masked/padded image is bit-exact
+// (data/dataset.py:41-47, data/tools.py:103-126, transforms/normalize.py:66-82).
+__global__ void mask_pad_normalize_kernel(MaskPadParams P)
+{
+    const long long total = (long long)P.B * P.res * P.res;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % P.res);
+        const long long r = i / P.res;
+        const int oy = (int)(r % P.res);
+        const int b = (int)(r / P.res);
+        const int iy = oy - P.y_top, ix = ox - P.x_left;
+        float v = 0.f;
+        if (iy >= 0 && iy < P.Hin && ix >= 0 && ix < P.Win) {
+            const long long src = ((long long)b * P.Hin + iy) * P.Win + ix;
+            v = P.counts_i32 ? (float)P.counts_i32[src] : P.counts_f32[src];
+            if (P.mask) v = v * (float)P.mask[(long long)iy * P.Win + ix];
+        }
+        if (P.do_norm) {
+            v = fminf(fmaxf(v, 0.f), P.max_val) / P.max_val;
+            v = stretch_fwd(v, P.mode);
+            v = fminf(fmaxf(v, 0.f), 1.f);
+        }
+        P.out[i] = v;
+    }
+}
+
+// Normalize.normalize_image with max_val > 0 / denormalize_image (normalize.py:66-92), elementwise.
+__global__ void normalize_kernel(const float* in, float* out, long long n, float max_val, int mode, int inverse)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = in[i];
+        if (!inverse) {
+            v = fminf(fmaxf(v, 0.f), max_val) / max_val;
+            v = stretch_fwd(v, mode);
+            v = fminf(fmaxf(v, 0.f), 1.f);
+        } else {
+            v = max_val * stretch_inv(v, mode);
+            v = fminf(fmaxf(v, 0.f), max_val);
+        }
+        out[i] = v;
+    }
+}
+
+// ImageUpsample: nearest x s then / s^2 (transforms/imageupsample.py:10-26); in [N][H][W] -> out [N][sH][sW]
+__global__ void upsample_nearest_kernel(const float* in, float* out, int N, int H, int W, int s)
+{
+    const long long total = (long long)N * H * s * W * s;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % (W * s));
+        const long long r = i / (W * s);
+        const int oy = (int)(r % (H * s));
+        const int nimg = (int)(r / (H * s));
+        out[i] = in[((long long)nimg * H + oy / s) * W + ox / s] / (float)(s * s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------------------------
+static inline int grid_for(long long n, int threads, int cap = 2048)
+{
+    long long g = (n + threads - 1) / threads;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+hipError_t launch_edge_expand(const EdgeExpandParams& p, hipStream_t s)
+{
+    const long long total = (long long)p.B * p.H * p.W * 8;
+    hipLaunchKernelGGL(edge_expand_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t launch_edge_reduce(const EdgeReduceParams& p, hipStream_t s)
+{
+    const long long total = (long long)p.B * p.H * p.W * 8;
+    hipLaunchKernelGGL(edge_reduce_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t launch_edge_wgrad(const EdgeWgradParams& p, int mode, float* dw, float* db, hipStream_t s)
+{
+    hipLaunchKernelGGL(edge_wgrad_kernel, dim3(p.nblocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(edge_wgrad_final_kernel, dim3(2), dim3(256), 0, s, p.partial, p.nblocks, mode, dw, db);
+    return hipGetLastError();
+}
+hipError_t launch_clamp_bwd(const float* pre, const float* dy, float* dpre, long long n, hipStream_t s)
+{
+    hipLaunchKernelGGL(clamp_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, pre, dy, dpre, n);
+    return hipGetLastError();
+}
+hipError_t launch_l1_loss(const float* y, const float* t, float* dy, double* partial, int nblocks, float* loss,
+                          long long n, hipStream_t s)
+{
+    hipLaunchKernelGGL(l1_loss_kernel, dim3(nblocks), dim3(256), 0, s, y, t, dy, partial, n, 1.0f / (float)n);
+    hipLaunchKernelGGL(l1_loss_final_kernel, dim3(1), dim3(64), 0, s, partial, nblocks, loss, 1.0 / (double)n);
+    return hipGetLastError();
+}
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, long long n, int step, float lr, float b1, float b2,
+                       float eps, float gscale, hipStream_t s)
+{
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, m, v, n, (float)(lr / bc1),
+                       (float)(1.0 / sqrt(bc2)), b1, b2, eps, gscale);
+    return hipGetLastError();
+}
+hipError_t launch_pack_weights(const float* params, const PackDesc* descs_dev, int ndesc, float* fwd, float* bwd,
+                               hipStream_t s)
+{
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(36, ndesc), dim3(256), 0, s, params, descs_dev, fwd, bwd);
+    return hipGetLastError();
+}
+hipError_t launch_pack_edge(const float* w_first, const float* w_last, float* ff, float* fb, float* lf, float* lb,
+                            hipStream_t s)
+{
+    hipLaunchKernelGGL(pack_edge_kernel, dim3(2), dim3(256), 0, s, w_first, w_last, ff, fb, lf, lb);
+    return hipGetLastError();
+}
+hipError_t launch_pack_shuffle_bias(const float* b, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(pack_shuffle_bias_kernel, dim3(1), dim3(128), 0, s, b, out);
+    return hipGetLastError();
+}
+hipError_t launch_mask_pad_normalize(const MaskPadParams& p, hipStream_t s)
+{
+    const long long total = (long long)p.B * p.res * p.res;
+    hipLaunchKernelGGL(mask_pad_normalize_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t launch_normalize(const float* in, float* out, long long n, float max_val, int mode, int inverse, hipStream_t s)
+{
+    hipLaunchKernelGGL(normalize_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, in, out, n, max_val, mode, inverse);
+    return hipGetLastError();
+}
+hipError_t launch_upsample_nearest(const float* in, float* out, int N, int H, int W, int sc, hipStream_t s)
+{
+    const long long total = (long long)N * H * sc * W * sc;
+    hipLaunchKernelGGL(upsample_nearest_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, out, N, H, W, sc);
+    return hipGetLastError();
+}
+
+} // namespace xsd

@@ -1,0 +1,764 @@
+// xsd_engine.hip -- host side of the engine: network plan (forward / backward launch schedules over feature planes),
+// workspace, weight packing, and the C ABI declared in include/xsd.h.
+//
+// The schedule restates, layer by layer, the reference graph
+//   _GeneratorRRDB.forward / GeneratorRRDB_SR.forward / GeneratorRRDB_DN.forward (generator_rrdb.py:66-69,103-110,130-137)
+//   RRDB.forward / ResidualDenseBlock_5C.forward                                   (rrdb_blocks.py:37-54,66-70)
+//   Model.forward's second clamp                                                   (models/model.py:48-49)
+// and its reverse-mode derivative (what torch autograd would run), with every elementwise op fused into the epilogue
+// of the conv that produces its operand.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/xsd.h"
+#include "xsd_aux.h"
+#include "xsd_kernels.h"
+
+using namespace xsd;
+
+namespace xsd {
+hipError_t launch_pack_shuffle_bias(const float* b, float* out, hipStream_t s);
+}
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) return fail(XSD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct ConvW {       // one MFMA conv's weights
+    long long w_off, b_off; // flat-param offsets
+    int cout, cin, shuffle;
+    long long fwd_off, bwd_off; // packed offsets (floats)
+    long long sbias_off;        // shuffled-bias offset (shuffle convs) or -1
+};
+
+typedef std::function<hipError_t(hipStream_t)> Launch;
+
+struct ProfRec { hipEvent_t a, b; double flop, bytes; int klass; };
+
+struct xsd_engine {
+    xsd_config cfg;
+    long long nparams = 0;
+    // flat-param offsets
+    long long first_w = 0, first_b = 0, last_w = 0, last_b = 0;
+    std::vector<ConvW> rdb; // blocks*15
+    ConvW trunk, hr;
+    std::vector<ConvW> up;
+    std::vector<long long> rrdb_begin; // flat offset where rrdb.i starts; [blocks] = trunk offset
+    // packed weights
+    float* pk_fwd = nullptr;
+    float* pk_bwd = nullptr;
+    float* pk_edge = nullptr; // first_fwd, first_bwd, last_fwd, last_bwd (288 each)
+    float* pk_sbias = nullptr;
+    PackDesc* descs_dev = nullptr;
+    int ndesc = 0;
+    long long pk_floats = 0;
+    const float* params = nullptr; // borrowed (bias reads)
+    bool packed = false;
+    // workspace
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    float* wg_partial = nullptr;
+    float* wg_bias_partial = nullptr;
+    float* edge_partial = nullptr;
+    double* loss_partial = nullptr;
+    int nparts = 256;
+    // plan
+    int pB = 0, pH = 0, pW = 0, ptrain = -1;
+    std::vector<Launch> fwd_ops;
+    std::vector<std::vector<Launch>> bwd_stages;
+    bool fwd_saved = false;
+    // late-bound call pointers
+    const float* b_x = nullptr;
+    float* b_y = nullptr;
+    const float* b_dy = nullptr;
+    float* b_dx = nullptr;
+    float* b_grads = nullptr;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+static void take_conv(long long& off, int cout, int cin, long long& w, long long& b)
+{
+    w = off; off += (long long)cout * cin * 9;
+    b = off; off += cout;
+}
+
+static hipError_t prof_launch(xsd_engine* e, int klass, double flop, double bytes, hipStream_t s, const std::function<hipError_t()>& f)
+{
+    if (!e->prof) return f();
+    auto get_ev = [&]() -> hipEvent_t {
+        if (e->ev_used == e->ev_pool.size()) {
+            hipEvent_t ev;
+            if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+            e->ev_pool.push_back(ev);
+        }
+        return e->ev_pool[e->ev_used++];
+    };
+    ProfRec r{get_ev(), get_ev(), flop, bytes, klass};
+    if (!r.a || !r.b) return hipErrorOutOfMemory;
+    hipEventRecord(r.a, s);
+    hipError_t err = f();
+    hipEventRecord(r.b, s);
+    e->recs.push_back(r);
+    return err;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Plan builder
+// ------------------------------------------------------------------------------------------------------------
+struct Builder {
+    xsd_engine* e;
+    int B, H, W;
+    bool train;
+    uintptr_t base;      // 0 in the sizing pass
+    size_t top = 0, peak = 0;
+    std::vector<std::vector<size_t>> freelist; // per level
+    Builder(xsd_engine* e_, int B_, int H_, int W_, bool train_, uintptr_t base_)
+        : e(e_), B(B_), H(H_), W(W_), train(train_), base(base_), freelist(8) {}
+
+    size_t plane_bytes(int level, int ch = 32) const
+    {
+        return ((size_t)B * (H << level) * (W << level) * ch * sizeof(float) + 255) & ~(size_t)255;
+    }
+    float* alloc(int level)
+    {
+        size_t off;
+        if (!freelist[level].empty()) { off = freelist[level].back(); freelist[level].pop_back(); }
+        else { off = top; top += plane_bytes(level); if (top > peak) peak = top; }
+        return reinterpret_cast<float*>(base + off);
+    }
+    float* alloc1(int level) // 1-channel image
+    {
+        size_t off = top; top += plane_bytes(level, 1); if (top > peak) peak = top;
+        return reinterpret_cast<float*>(base + off);
+    }
+    void release(float* p, int level, bool force = false)
+    {
+        if (train && !force) return; // saved for backward
+        freelist[level].push_back(reinterpret_cast<uintptr_t>(p) - base);
+    }
+
+    ConvParams conv_base(int level) const
+    {
+        ConvParams p;
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.H = H << level; p.W = W << level;
+        p.tilesX = (p.W + TILE_W - 1) / TILE_W;
+        p.tilesY = (p.H + TILE_H - 1) / TILE_H;
+        p.std_rs = p.W * 32;
+        p.std_bs = (long long)p.H * p.W * 32;
+        for (int j = 0; j < 5; ++j) { p.out[j].a1 = 1.f; p.out[j].a2 = 1.f; p.out[j].slope = 1.f; p.out[j].mslope = 1.f; }
+        return p;
+    }
+    PlaneIn std_in(const float* p, int level) const
+    {
+        PlaneIn r; r.p = p; r.ps = 32; r.rs = (W << level) * 32; r.bs = (long long)(H << level) * (W << level) * 32; return r;
+    }
+    // sub-pixel (i,j) view at `level` of a plane stored at level+1 (PixelShuffle(2), generator_rrdb.py:97)
+    PlaneIn shuf_in(const float* hr, int level, int n) const
+    {
+        const int Wl = W << level, Hl = H << level;
+        PlaneIn r; r.p = hr + ((long long)(n >> 1) * 2 * Wl + (n & 1)) * 32; r.ps = 64; r.rs = 4 * Wl * 32;
+        r.bs = (long long)4 * Hl * Wl * 32; return r;
+    }
+    void std_out(OutDesc& o, float* p, int level) const
+    {
+        o.p = p; o.ps = 32; o.rs = (W << level) * 32; o.bs = (long long)(H << level) * (W << level) * 32;
+    }
+    void shuf_out(OutDesc& o, float* hr, int level, int n) const
+    {
+        PlaneIn r = shuf_in(hr, level, n);
+        o.p = const_cast<float*>(r.p); o.ps = r.ps; o.rs = r.rs; o.bs = r.bs;
+    }
+
+    Launch conv_launch(const ConvParams& p_in, bool bias_from_params, long long bias_off)
+    {
+        ConvParams p = p_in;
+        xsd_engine* eng = e;
+        const double px = (double)p.B * p.H * p.W;
+        const double flop = 2.0 * 9 * 32 * 32 * p.n_in * p.n_out * px;
+        const double bytes = 128.0 * (p.n_in + p.n_out) * px;
+        return [eng, p, bias_from_params, bias_off, flop, bytes](hipStream_t s) mutable {
+            if (bias_from_params) p.bias = eng->params + bias_off;
+            return prof_launch(eng, 0, flop, bytes, s, [&]() { return launch_conv3x3_mfma(p, s); });
+        };
+    }
+    // wgrad + fixed-order reduce into the flat gradient vector
+    void wgrad_launch(std::vector<Launch>& ops, int level, const std::vector<PlaneIn>& xs, const std::vector<PlaneIn>& gs,
+                      const ConvW& cw, float scale)
+    {
+        xsd_engine* eng = e;
+        WgradParams wp;
+        memset(&wp, 0, sizeof(wp));
+        wp.B = B; wp.H = H << level; wp.W = W << level;
+        wp.tilesX = (wp.W + TILE_W - 1) / TILE_W; wp.tilesY = (wp.H + TILE_H - 1) / TILE_H;
+        wp.n_in = (int)xs.size(); wp.n_g = (int)gs.size(); wp.nparts = e->nparts;
+        for (size_t i = 0; i < xs.size(); ++i) wp.x[i] = xs[i];
+        for (size_t i = 0; i < gs.size(); ++i) wp.g[i] = gs[i];
+        WgradReduceParams rp;
+        memset(&rp, 0, sizeof(rp));
+        rp.nparts = e->nparts; rp.n_in = wp.n_in; rp.n_g = wp.n_g; rp.cin_total = cw.cin; rp.cout_total = cw.cout;
+        rp.shuffle = cw.shuffle; rp.scale = scale;
+        const long long w_off = cw.w_off, b_off = cw.b_off;
+        const double px = (double)wp.B * wp.H * wp.W;
+        const double flop = 2.0 * 9 * 32 * 32 * wp.n_in * wp.n_g * px;
+        const double bytes = 128.0 * 2 * wp.n_in * wp.n_g * px;
+        ops.push_back([eng, wp, rp, w_off, b_off, flop, bytes](hipStream_t s) mutable {
+            wp.partial = eng->wg_partial; wp.bias_partial = eng->wg_bias_partial;
+            rp.partial = eng->wg_partial; rp.bias_partial = eng->wg_bias_partial;
+            rp.dw = eng->b_grads + w_off; rp.db = eng->b_grads + b_off;
+            hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return launch_wgrad_mfma(wp, s); });
+            if (err != hipSuccess) return err;
+            return launch_wgrad_reduce(rp, s);
+        });
+    }
+
+    // ---------------------------------------------------------------------------------------------------------
+    void build()
+    {
+        xsd_engine* eng = e;
+        const int blocks = e->cfg.num_res_blocks;
+        const bool sr = e->cfg.kind == XSD_KIND_SR;
+        const int nup = sr ? e->cfg.num_upsample : 0;
+        std::vector<Launch>& F = e->fwd_ops;
+        F.clear();
+        e->bwd_stages.assign(blocks + 2, {});
+
+        struct RdbAct { float* xin; float* xs[4]; float* out; };
+        std::vector<RdbAct> acts(blocks * 3);
+        std::vector<float*> rin(blocks + 1);
+
+        // ---- forward ------------------------------------------------------------------------------------------
+        float* fea = alloc(0);
+        { // conv_first (generator_rrdb.py:67)
+            EdgeExpandParams p; memset(&p, 0, sizeof(p));
+            p.B = B; p.H = H; p.W = W; p.out = fea; p.w = e->pk_edge + 0; p.mslope = 1.f;
+            const long long boff = e->first_b;
+            F.push_back([eng, p, boff](hipStream_t s) mutable { p.s = eng->b_x; p.bias = eng->params + boff; return launch_edge_expand(p, s); });
+        }
+        float* cur = fea;
+        for (int i = 0; i < blocks; ++i) {
+            rin[i] = cur;
+            for (int r = 0; r < 3; ++r) {
+                RdbAct& a = acts[i * 3 + r];
+                a.xin = cur;
+                for (int c = 0; c < 5; ++c) {
+                    const ConvW& cw = e->rdb[(i * 3 + r) * 5 + c];
+                    ConvParams p = conv_base(0);
+                    p.n_in = c + 1; p.n_out = 1;
+                    p.in[0] = std_in(a.xin, 0);
+                    for (int k = 0; k < c; ++k) p.in[k + 1] = std_in(a.xs[k], 0);
+                    p.wpanel = e->pk_fwd + cw.fwd_off;
+                    float* o = alloc(0);
+                    std_out(p.out[0], o, 0);
+                    if (c < 4) { p.out[0].slope = 0.2f; a.xs[c] = o; }     // rrdb_blocks.py:38-52
+                    else {
+                        p.out[0].a1 = 0.2f; p.out[0].e1 = a.xin; p.out[0].s1 = 1.f;           // x5*0.2 + x   (:54)
+                        if (r == 2) { p.out[0].a2 = 0.2f; p.out[0].e2 = rin[i]; p.out[0].s2 = 1.f; } // out*0.2 + x (:70)
+                        a.out = o;
+                    }
+                    F.push_back(conv_launch(p, true, cw.b_off));
+                }
+                for (int k = 0; k < 4; ++k) release(a.xs[k], 0);
+                if (r > 0) release(a.xin, 0);
+                cur = a.out;
+            }
+            if (i > 0) release(rin[i], 0);
+        }
+        rin[blocks] = cur;
+        float* T = alloc(0);
+        { // fea + trunk_conv(rrdb(fea)) (generator_rrdb.py:68-69)
+            ConvParams p = conv_base(0);
+            p.n_in = 1; p.n_out = 1; p.in[0] = std_in(cur, 0); p.wpanel = e->pk_fwd + e->trunk.fwd_off;
+            std_out(p.out[0], T, 0);
+            p.out[0].e1 = fea; p.out[0].s1 = 1.f;
+            F.push_back(conv_launch(p, true, e->trunk.b_off));
+        }
+        if (blocks > 0) release(cur, 0);
+        release(fea, 0);
+
+        std::vector<float*> U(nup, nullptr);
+        float* H1 = nullptr;
+        float* pre = nullptr;
+        const int lo = nup; // output level
+        if (sr) {
+            const float* feat = T;
+            for (int u = 0; u < nup; ++u) { // upsampling: conv 32->128, LeakyReLU(0.01), PixelShuffle(2) (generator_rrdb.py:93-99)
+                U[u] = alloc(u + 1);
+                ConvParams p = conv_base(u);
+                p.n_in = 1; p.n_out = 4; p.in[0] = std_in(feat, u); p.wpanel = e->pk_fwd + e->up[u].fwd_off;
+                for (int n = 0; n < 4; ++n) { shuf_out(p.out[n], U[u], u, n); p.out[n].slope = 0.01f; }
+                p.bias = e->pk_sbias + e->up[u].sbias_off;
+                F.push_back(conv_launch(p, false, 0));
+                release(const_cast<float*>(feat), u);
+                feat = U[u];
+            }
+            H1 = alloc(lo);
+            { // lrelu(HRconv(fea)) (generator_rrdb.py:107)
+                ConvParams p = conv_base(lo);
+                p.n_in = 1; p.n_out = 1; p.in[0] = std_in(feat, lo); p.wpanel = e->pk_fwd + e->hr.fwd_off;
+                std_out(p.out[0], H1, lo); p.out[0].slope = 0.2f;
+                F.push_back(conv_launch(p, true, e->hr.b_off));
+            }
+            if (nup > 0) release(U[nup - 1], lo); else release(T, 0);
+        }
+        pre = train ? alloc1(lo) : nullptr;
+        { // conv_last (+x for DN) + clamp, clamp (generator_rrdb.py:107-108,132-135; model.py:49)
+            EdgeReduceParams p; memset(&p, 0, sizeof(p));
+            p.B = B; p.H = H << lo; p.W = W << lo; p.f = sr ? H1 : T; p.w = e->pk_edge + 2 * 288; p.pre = pre; p.clamp01 = 1;
+            const long long boff = e->last_b;
+            F.push_back([eng, p, boff, sr](hipStream_t s) mutable {
+                p.bias = eng->params + boff; p.skip = sr ? nullptr : eng->b_x; p.y = eng->b_y; return launch_edge_reduce(p, s);
+            });
+        }
+        if (!train) return;
+
+        // ---- backward -----------------------------------------------------------------------------------------
+        float* dpre = alloc1(lo);
+        float* dT = alloc(0);
+        { // stage 0: output head
+            std::vector<Launch>& S = e->bwd_stages[0];
+            const long long npx = (long long)B * (H << lo) * (W << lo);
+            S.push_back([eng, pre, dpre, npx](hipStream_t s) { return launch_clamp_bwd(pre, eng->b_dy, dpre, npx, s); });
+            { // conv_last weight grad
+                EdgeWgradParams p; memset(&p, 0, sizeof(p));
+                p.B = B; p.H = H << lo; p.W = W << lo; p.f = sr ? H1 : T; p.s = dpre; p.nblocks = 512;
+                const long long wo = e->last_w, bo = e->last_b;
+                S.push_back([eng, p, wo, bo](hipStream_t s) mutable {
+                    p.partial = eng->edge_partial; return launch_edge_wgrad(p, 1, eng->b_grads + wo, eng->b_grads + bo, s);
+                });
+            }
+            if (!sr) {
+                EdgeExpandParams p; memset(&p, 0, sizeof(p));
+                p.B = B; p.H = H; p.W = W; p.s = dpre; p.w = e->pk_edge + 3 * 288; p.out = dT; p.mslope = 1.f;
+                S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
+            } else {
+                float* GH = alloc(lo);
+                { // d(H1) masked by lrelu'(0.2)
+                    EdgeExpandParams p; memset(&p, 0, sizeof(p));
+                    p.B = B; p.H = H << lo; p.W = W << lo; p.s = dpre; p.w = e->pk_edge + 3 * 288; p.out = GH; p.mask = H1; p.mslope = 0.2f;
+                    S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
+                }
+                const float* hr_in = nup > 0 ? U[nup - 1] : T;
+                wgrad_launch(S, lo, {std_in(hr_in, lo)}, {std_in(GH, lo)}, e->hr, 1.f);
+                float* G = nup > 0 ? alloc(lo) : dT;
+                { // HRconv input gradient (masked by the upsample LeakyReLU(0.01) when it feeds a pixel-shuffle)
+                    ConvParams p = conv_base(lo);
+                    p.n_in = 1; p.n_out = 1; p.in[0] = std_in(GH, lo); p.wpanel = e->pk_bwd + e->hr.bwd_off;
+                    std_out(p.out[0], G, lo);
+                    if (nup > 0) { p.out[0].mask = U[nup - 1]; p.out[0].mslope = 0.01f; }
+                    S.push_back(conv_launch(p, false, 0));
+                }
+                for (int u = nup - 1; u >= 0; --u) {
+                    const float* xin = u > 0 ? U[u - 1] : T;
+                    std::vector<PlaneIn> gs;
+                    for (int n = 0; n < 4; ++n) gs.push_back(shuf_in(G, u, n));
+                    wgrad_launch(S, u, {std_in(xin, u)}, gs, e->up[u], 1.f);
+                    float* Gn = u > 0 ? alloc(u) : dT;
+                    ConvParams p = conv_base(u);
+                    p.n_in = 4; p.n_out = 1;
+                    for (int n = 0; n < 4; ++n) p.in[n] = gs[n];
+                    p.wpanel = e->pk_bwd + e->up[u].bwd_off;
+                    std_out(p.out[0], Gn, u);
+                    if (u > 0) { p.out[0].mask = U[u - 1]; p.out[0].mslope = 0.01f; }
+                    S.push_back(conv_launch(p, false, 0));
+                    G = Gn;
+                }
+            }
+            // trunk_conv
+            wgrad_launch(S, 0, {std_in(rin[blocks], 0)}, {std_in(dT, 0)}, e->trunk, 1.f);
+        }
+        float* dR = alloc(0);
+        {
+            ConvParams p = conv_base(0);
+            p.n_in = 1; p.n_out = 1; p.in[0] = std_in(dT, 0); p.wpanel = e->pk_bwd + e->trunk.bwd_off;
+            std_out(p.out[0], dR, 0);
+            e->bwd_stages[0].push_back(conv_launch(p, false, 0));
+        }
+        float* dS[5] = {nullptr, alloc(0), alloc(0), alloc(0), alloc(0)};
+        for (int i = blocks - 1; i >= 0; --i) {
+            std::vector<Launch>& S = e->bwd_stages[blocks - i];
+            float* dOut = dR;
+            for (int r = 2; r >= 0; --r) {
+                const RdbAct& a = acts[i * 3 + r];
+                const float gscale = r == 2 ? 0.04f : 0.2f;
+                const ConvW* cw = &e->rdb[(i * 3 + r) * 5];
+                dS[0] = alloc(0);
+                const float* xpl[5] = {a.xin, a.xs[0], a.xs[1], a.xs[2], a.xs[3]};
+                for (int c = 4; c >= 0; --c) {
+                    const float* G = c == 4 ? dOut : dS[c + 1];
+                    std::vector<PlaneIn> xs;
+                    for (int k = 0; k <= c; ++k) xs.push_back(std_in(xpl[k], 0));
+                    wgrad_launch(S, 0, xs, {std_in(G, 0)}, cw[c], c == 4 ? gscale : 1.f);
+                    ConvParams p = conv_base(0);
+                    p.n_in = 1; p.n_out = c + 1; p.in[0] = std_in(G, 0); p.wpanel = e->pk_bwd + cw[c].bwd_off;
+                    for (int j = 0; j <= c; ++j) {
+                        OutDesc& o = p.out[j];
+                        std_out(o, dS[j], 0);
+                        if (c == 4) {
+                            o.a1 = gscale;
+                            if (j == 0) {
+                                o.e1 = dOut; o.s1 = r == 2 ? 0.2f : 1.f;
+                                if (r == 0) { o.e2 = dR; o.s2 = 1.f; if (i == 0) { o.e3 = dT; o.s3 = 1.f; } }
+                            }
+                        } else o.accumulate = 1;
+                        if (j == c && j >= 1) { o.mask = xpl[j]; o.mslope = 0.2f; } // last contribution to d(x_j): apply lrelu'
+                    }
+                    S.push_back(conv_launch(p, false, 0));
+                }
+                if (dOut != dR) release(dOut, 0, true);
+                dOut = dS[0];
+            }
+            release(dR, 0, true);
+            dR = dOut;
+        }
+        { // last stage: conv_first weight grad and (optionally) dx
+            std::vector<Launch>& S = e->bwd_stages[blocks + 1];
+            float* dFea = dR; // when blocks == 0 this is d(rrdb out) and needs + dT; blocks >= 1 is enforced at create
+            EdgeWgradParams p; memset(&p, 0, sizeof(p));
+            p.B = B; p.H = H; p.W = W; p.f = dFea; p.nblocks = 512;
+            const long long wo = e->first_w, bo = e->first_b;
+            S.push_back([eng, p, wo, bo](hipStream_t s) mutable {
+                p.s = eng->b_x; p.partial = eng->edge_partial; return launch_edge_wgrad(p, 0, eng->b_grads + wo, eng->b_grads + bo, s);
+            });
+            EdgeReduceParams q; memset(&q, 0, sizeof(q));
+            q.B = B; q.H = H; q.W = W; q.f = dFea; q.w = e->pk_edge + 1 * 288; q.clamp01 = 0;
+            const float* skipg = sr ? nullptr : dpre;
+            S.push_back([eng, q, skipg](hipStream_t s) mutable {
+                if (!eng->b_dx) return hipSuccess;
+                q.addto = skipg; q.y = eng->b_dx; return launch_edge_reduce(q, s);
+            });
+        }
+    }
+};
+
+static int ensure_plan(xsd_engine* e, int B, int H, int W, bool train)
+{
+    if (e->pB == B && e->pH == H && e->pW == W && e->ptrain == (int)train) return XSD_OK;
+    e->pB = e->pH = e->pW = 0; e->ptrain = -1; e->fwd_saved = false;
+    Builder sizing(e, B, H, W, train, 0);
+    sizing.build();
+    const size_t need = sizing.peak + 256;
+    if (need > e->ws_bytes) {
+        if (e->ws) { hipDeviceSynchronize(); hipFree(e->ws); e->ws = nullptr; e->ws_bytes = 0; }
+        hipError_t err = hipMalloc((void**)&e->ws, need);
+        if (err != hipSuccess) return fail(XSD_ERR_NOMEM, "workspace hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(err));
+        e->ws_bytes = need;
+    }
+    Builder real(e, B, H, W, train, reinterpret_cast<uintptr_t>(e->ws));
+    real.build();
+    e->pB = B; e->pH = H; e->pW = W; e->ptrain = (int)train;
+    return XSD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* xsd_last_error(void) { return g_err.c_str(); }
+const char* xsd_version(void) { return "xsd-hip gfx950 r1"; }
+
+int xsd_create(const xsd_config* cfg, xsd_engine** out)
+{
+    if (!cfg || !out) return fail(XSD_ERR_ARG, "null argument");
+    if (cfg->kind != XSD_KIND_DN && cfg->kind != XSD_KIND_SR) return fail(XSD_ERR_ARG, "kind must be 0 (DN) or 1 (SR)");
+    if (cfg->in_channels != 1 || cfg->out_channels != 1) return fail(XSD_ERR_ARG, "engine supports in_channels = out_channels = 1 (got %d,%d)", cfg->in_channels, cfg->out_channels);
+    if (cfg->num_filters != 32) return fail(XSD_ERR_ARG, "engine is specialised for num_filters = 32 (got %d)", cfg->num_filters);
+    if (cfg->num_res_blocks < 1 || cfg->num_res_blocks > 64) return fail(XSD_ERR_ARG, "num_res_blocks must be in [1,64]");
+    if (cfg->kind == XSD_KIND_SR && (cfg->num_upsample < 1 || cfg->num_upsample > 2)) return fail(XSD_ERR_ARG, "num_upsample must be 1 or 2");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(XSD_ERR_HIP, "no HIP device available");
+    xsd_engine* e = new xsd_engine();
+    e->cfg = *cfg;
+    const int blocks = cfg->num_res_blocks, nup = cfg->kind == XSD_KIND_SR ? cfg->num_upsample : 0;
+    long long off = 0, pk = 0, sb = 0;
+    take_conv(off, 32, 1, e->first_w, e->first_b);
+    auto mk = [&](int cout, int cin, int shuffle) {
+        ConvW c; take_conv(off, cout, cin, c.w_off, c.b_off);
+        c.cout = cout; c.cin = cin; c.shuffle = shuffle;
+        c.fwd_off = pk; c.bwd_off = pk; pk += (long long)(cout / 32) * (cin / 32) * PANEL_FLOATS;
+        c.sbias_off = -1;
+        if (shuffle) { c.sbias_off = sb; sb += cout; }
+        return c;
+    };
+    for (int i = 0; i < blocks; ++i) {
+        e->rrdb_begin.push_back(off);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 5; ++c) e->rdb.push_back(mk(32, 32 * (c + 1), 0));
+    }
+    e->rrdb_begin.push_back(off);
+    e->trunk = mk(32, 32, 0);
+    take_conv(off, 1, 32, e->last_w, e->last_b);
+    for (int u = 0; u < nup; ++u) e->up.push_back(mk(128, 32, 1));
+    if (cfg->kind == XSD_KIND_SR) e->hr = mk(32, 32, 0);
+    e->nparams = off;
+    e->pk_floats = pk;
+
+    std::vector<PackDesc> descs;
+    auto add = [&](const ConvW& c) { PackDesc d; d.src_w = c.w_off; d.dst_fwd = c.fwd_off; d.dst_bwd = c.bwd_off; d.cout = c.cout; d.cin = c.cin; d.shuffle = c.shuffle; d.pad = 0; descs.push_back(d); };
+    for (auto& c : e->rdb) add(c);
+    add(e->trunk);
+    for (auto& c : e->up) add(c);
+    if (cfg->kind == XSD_KIND_SR) add(e->hr);
+    e->ndesc = (int)descs.size();
+#define CK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { int rc = fail(XSD_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); xsd_destroy(e); return rc; } } while (0)
+    CK(hipMalloc((void**)&e->pk_fwd, sizeof(float) * pk));
+    CK(hipMalloc((void**)&e->pk_bwd, sizeof(float) * pk));
+    CK(hipMalloc((void**)&e->pk_edge, sizeof(float) * 4 * 288));
+    CK(hipMalloc((void**)&e->pk_sbias, sizeof(float) * (sb ? sb : 1)));
+    CK(hipMalloc((void**)&e->descs_dev, sizeof(PackDesc) * descs.size()));
+    CK(hipMemcpy(e->descs_dev, descs.data(), sizeof(PackDesc) * descs.size(), hipMemcpyHostToDevice));
+    CK(hipMalloc((void**)&e->wg_partial, sizeof(float) * (size_t)e->nparts * 5 * PANEL_FLOATS));
+    CK(hipMalloc((void**)&e->wg_bias_partial, sizeof(float) * (size_t)e->nparts * 4 * 32));
+    CK(hipMalloc((void**)&e->edge_partial, sizeof(float) * 512 * 321));
+    CK(hipMalloc((void**)&e->loss_partial, sizeof(double) * 1024));
+#undef CK
+    *out = e;
+    return XSD_OK;
+}
+
+void xsd_destroy(xsd_engine* e)
+{
+    if (!e) return;
+    hipDeviceSynchronize();
+    for (auto ev : e->ev_pool) hipEventDestroy(ev);
+    hipFree(e->pk_fwd); hipFree(e->pk_bwd); hipFree(e->pk_edge); hipFree(e->pk_sbias); hipFree(e->descs_dev);
+    hipFree(e->wg_partial); hipFree(e->wg_bias_partial); hipFree(e->edge_partial); hipFree(e->loss_partial);
+    hipFree(e->ws);
+    delete e;
+}
+
+int64_t xsd_param_count(const xsd_engine* e) { return e ? e->nparams : 0; }
+
+int xsd_pack_weights(xsd_engine* e, const float* dev_params, void* stream)
+{
+    if (!e || !dev_params) return fail(XSD_ERR_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    e->params = dev_params;
+    HIPCHK(launch_pack_weights(dev_params, e->descs_dev, e->ndesc, e->pk_fwd, e->pk_bwd, s));
+    HIPCHK(launch_pack_edge(dev_params + e->first_w, dev_params + e->last_w, e->pk_edge, e->pk_edge + 288, e->pk_edge + 576,
+                            e->pk_edge + 864, s));
+    for (auto& c : e->up) HIPCHK(launch_pack_shuffle_bias(dev_params + c.b_off, e->pk_sbias + c.sbias_off, s));
+    e->packed = true;
+    return XSD_OK;
+}
+
+int xsd_forward(xsd_engine* e, const float* dev_x, float* dev_y, int B, int H, int W, int save_for_backward, void* stream)
+{
+    if (!e || !dev_x || !dev_y) return fail(XSD_ERR_ARG, "null argument");
+    if (B < 1 || H < 1 || W < 1) return fail(XSD_ERR_ARG, "bad shape %dx%dx%d", B, H, W);
+    if (!e->packed) return fail(XSD_ERR_STATE, "xsd_pack_weights must be called before xsd_forward");
+    const int lo = e->cfg.kind == XSD_KIND_SR ? e->cfg.num_upsample : 0;
+    if ((long long)(H << lo) * (W << lo) * 32 >= (1ll << 31)) return fail(XSD_ERR_ARG, "image too large for 32-bit in-image offsets");
+    int rc = ensure_plan(e, B, H, W, save_for_backward != 0);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    e->b_x = dev_x; e->b_y = dev_y;
+    for (auto& op : e->fwd_ops) HIPCHK(op(s));
+    e->fwd_saved = save_for_backward != 0;
+    return XSD_OK;
+}
+
+int xsd_backward_num_stages(const xsd_engine* e) { return e ? e->cfg.num_res_blocks + 2 : 0; }
+
+int xsd_backward_stage(xsd_engine* e, int stage, const float* dev_dy, float* dev_dx_or_null, float* dev_grads, void* stream)
+{
+    if (!e || !dev_dy || !dev_grads) return fail(XSD_ERR_ARG, "null argument");
+    if (!e->fwd_saved) return fail(XSD_ERR_STATE, "xsd_backward needs a preceding xsd_forward(save_for_backward=1)");
+    if (stage < 0 || stage >= (int)e->bwd_stages.size()) return fail(XSD_ERR_ARG, "stage %d out of range", stage);
+    hipStream_t s = (hipStream_t)stream;
+    e->b_dy = dev_dy; e->b_dx = dev_dx_or_null; e->b_grads = dev_grads;
+    for (auto& op : e->bwd_stages[stage]) HIPCHK(op(s));
+    return XSD_OK;
+}
+
+int xsd_backward(xsd_engine* e, const float* dev_dy, float* dev_dx_or_null, float* dev_grads, void* stream)
+{
+    const int n = xsd_backward_num_stages(e);
+    for (int st = 0; st < n; ++st) {
+        int rc = xsd_backward_stage(e, st, dev_dy, dev_dx_or_null, dev_grads, stream);
+        if (rc) return rc;
+    }
+    return XSD_OK;
+}
+
+int xsd_grad_range(const xsd_engine* e, int stage, int range_idx, int64_t* offset, int64_t* count)
+{
+    if (!e) return 0;
+    const int blocks = e->cfg.num_res_blocks;
+    if (range_idx != 0 || stage < 0 || stage > blocks + 1) return 1;
+    long long a, b;
+    if (stage == 0) { a = e->rrdb_begin[blocks]; b = e->nparams; }
+    else if (stage <= blocks) { const int i = blocks - stage; a = e->rrdb_begin[i]; b = e->rrdb_begin[i + 1]; }
+    else { a = 0; b = e->rrdb_begin[0]; }
+    if (offset) *offset = a;
+    if (count) *count = b - a;
+    return 1;
+}
+
+int xsd_l1_loss(xsd_engine* e, const float* dev_y, const float* dev_target, float* dev_dy_or_null, float* dev_loss, int64_t n, void* stream)
+{
+    if (!e || !dev_y || !dev_target || !dev_loss || n <= 0) return fail(XSD_ERR_ARG, "bad argument");
+    HIPCHK(launch_l1_loss(dev_y, dev_target, dev_dy_or_null, e->loss_partial, 1024, dev_loss, n, (hipStream_t)stream));
+    return XSD_OK;
+}
+
+int xsd_adam_step(xsd_engine* e, float* dev_params, const float* dev_grads, float* dev_m, float* dev_v, int64_t n, int step,
+                  float lr, float beta1, float beta2, float eps, float grad_scale, void* stream)
+{
+    (void)e;
+    if (!dev_params || !dev_grads || !dev_m || !dev_v || n <= 0 || step < 1) return fail(XSD_ERR_ARG, "bad argument");
+    HIPCHK(launch_adam(dev_params, dev_grads, dev_m, dev_v, n, step, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream));
+    return XSD_OK;
+}
+
+int xsd_mask_pad_normalize(const void* dev_counts, int counts_is_int32, const uint8_t* dev_mask_or_null, float* dev_out, int B,
+                           int Hin, int Win, int res, int do_normalize, float max_val, int stretch, void* stream)
+{
+    if (!dev_counts || !dev_out || B < 1 || Hin < 1 || Win < 1 || res < 1) return fail(XSD_ERR_ARG, "bad argument");
+    if (stretch < 0 || stretch > 3) return fail(XSD_ERR_ARG, "stretch must be 0..3");
+    if (do_normalize && !(max_val > 0.f)) return fail(XSD_ERR_ARG, "max_val must be > 0 on the fused path");
+    MaskPadParams p; memset(&p, 0, sizeof(p));
+    if (counts_is_int32) p.counts_i32 = (const int32_t*)dev_counts; else p.counts_f32 = (const float*)dev_counts;
+    p.mask = dev_mask_or_null; p.out = dev_out; p.B = B; p.Hin = Hin; p.Win = Win; p.res = res;
+    p.y_top = (int)std::floor((res - Hin) / 2.0); p.x_left = (int)std::floor((res - Win) / 2.0);
+    p.do_norm = do_normalize; p.mode = stretch; p.max_val = max_val;
+    HIPCHK(launch_mask_pad_normalize(p, (hipStream_t)stream));
+    return XSD_OK;
+}
+
+int xsd_normalize(const float* dev_in, float* dev_out, int64_t n, float max_val, int stretch, int inverse, void* stream)
+{
+    if (!dev_in || !dev_out || n <= 0 || !(max_val > 0.f) || stretch < 0 || stretch > 3) return fail(XSD_ERR_ARG, "bad argument");
+    HIPCHK(launch_normalize(dev_in, dev_out, n, max_val, stretch, inverse, (hipStream_t)stream));
+    return XSD_OK;
+}
+
+int xsd_image_upsample(const float* dev_in, float* dev_out, int N, int H, int W, int scale, void* stream)
+{
+    if (!dev_in || !dev_out || N < 1 || H < 1 || W < 1 || scale < 1) return fail(XSD_ERR_ARG, "bad argument");
+    HIPCHK(launch_upsample_nearest(dev_in, dev_out, N, H, W, scale, (hipStream_t)stream));
+    return XSD_OK;
+}
+
+int xsd_profile_enable(xsd_engine* e, int enable)
+{
+    if (!e) return fail(XSD_ERR_ARG, "null engine");
+    hipDeviceSynchronize();
+    e->recs.clear(); e->ev_used = 0; e->prof = enable != 0;
+    return XSD_OK;
+}
+
+int xsd_profile_read(xsd_engine* e, int klass, double* total_ms, int64_t* launches, double* total_flop, double* total_bytes)
+{
+    if (!e) return fail(XSD_ERR_ARG, "null engine");
+    HIPCHK(hipDeviceSynchronize());
+    double ms = 0, fl = 0, by = 0; int64_t n = 0;
+    for (auto& r : e->recs) {
+        if (r.klass != klass) continue;
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
+        ms += t; fl += r.flop; by += r.bytes; ++n;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
+    if (total_flop) *total_flop = fl;
+    if (total_bytes) *total_bytes = by;
+    return XSD_OK;
+}
+
+// ---- single-layer test hooks ---------------------------------------------------------------------------------
+static int pack_single(const float* dev_w, int cout, int cin, float** fwd, float** bwd, hipStream_t s)
+{
+    const long long n = (long long)(cout / 32) * (cin / 32) * PANEL_FLOATS;
+    PackDesc d; d.src_w = 0; d.dst_fwd = 0; d.dst_bwd = 0; d.cout = cout; d.cin = cin; d.shuffle = 0; d.pad = 0;
+    PackDesc* dd = nullptr;
+    HIPCHK(hipMalloc((void**)fwd, sizeof(float) * n));
+    HIPCHK(hipMalloc((void**)bwd, sizeof(float) * n));
+    HIPCHK(hipMalloc((void**)&dd, sizeof(PackDesc)));
+    HIPCHK(hipMemcpy(dd, &d, sizeof(d), hipMemcpyHostToDevice));
+    HIPCHK(launch_pack_weights(dev_w, dd, 1, *fwd, *bwd, s));
+    HIPCHK(hipStreamSynchronize(s));
+    hipFree(dd);
+    return XSD_OK;
+}
+
+int xsd_test_conv3x3(xsd_engine* e, const float* const* in_planes, int n_in, const float* dev_w_oihw, const float* dev_bias,
+                     float* const* out_planes, int n_out, float slope, int B, int H, int W, void* stream)
+{
+    if (!e || n_in < 1 || n_in > 5 || n_out < 1 || n_out > 5 || (n_in > 1 && n_out > 1)) return fail(XSD_ERR_ARG, "bad n_in/n_out");
+    hipStream_t s = (hipStream_t)stream;
+    float *fwd = nullptr, *bwd = nullptr;
+    int rc = pack_single(dev_w_oihw, 32 * n_out, 32 * n_in, &fwd, &bwd, s);
+    if (rc) return rc;
+    Builder b(e, B, H, W, false, 0);
+    ConvParams p = b.conv_base(0);
+    p.n_in = n_in; p.n_out = n_out; p.wpanel = fwd; p.bias = dev_bias;
+    for (int i = 0; i < n_in; ++i) p.in[i] = b.std_in(in_planes[i], 0);
+    for (int j = 0; j < n_out; ++j) { b.std_out(p.out[j], out_planes[j], 0); p.out[j].slope = slope; }
+    hipError_t err = launch_conv3x3_mfma(p, s);
+    hipStreamSynchronize(s);
+    hipFree(fwd); hipFree(bwd);
+    if (err != hipSuccess) return fail(XSD_ERR_HIP, "conv launch: %s", hipGetErrorString(err));
+    return XSD_OK;
+}
+
+int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in, const float* dev_w_oihw, const float* dev_g_plane,
+                         float* const* dx_planes, float* dev_dw_oihw, float* dev_db, int B, int H, int W, void* stream)
+{
+    if (!e || n_in < 1 || n_in > 5) return fail(XSD_ERR_ARG, "bad n_in");
+    hipStream_t s = (hipStream_t)stream;
+    float *fwd = nullptr, *bwd = nullptr;
+    int rc = pack_single(dev_w_oihw, 32, 32 * n_in, &fwd, &bwd, s);
+    if (rc) return rc;
+    Builder b(e, B, H, W, false, 0);
+    ConvParams p = b.conv_base(0);
+    p.n_in = 1; p.n_out = n_in; p.wpanel = bwd; p.in[0] = b.std_in(dev_g_plane, 0);
+    for (int j = 0; j < n_in; ++j) b.std_out(p.out[j], dx_planes[j], 0);
+    hipError_t err = launch_conv3x3_mfma(p, s);
+    if (err == hipSuccess) {
+        WgradParams wp; memset(&wp, 0, sizeof(wp));
+        wp.B = B; wp.H = H; wp.W = W; wp.tilesX = p.tilesX; wp.tilesY = p.tilesY; wp.n_in = n_in; wp.n_g = 1; wp.nparts = e->nparts;
+        for (int i = 0; i < n_in; ++i) wp.x[i] = b.std_in(in_planes[i], 0);
+        wp.g[0] = b.std_in(dev_g_plane, 0);
+        wp.partial = e->wg_partial; wp.bias_partial = e->wg_bias_partial;
+        err = launch_wgrad_mfma(wp, s);
+        if (err == hipSuccess) {
+            WgradReduceParams rp; memset(&rp, 0, sizeof(rp));
+            rp.partial = e->wg_partial; rp.bias_partial = e->wg_bias_partial; rp.nparts = e->nparts; rp.n_in = n_in; rp.n_g = 1;
+            rp.cin_total = 32 * n_in; rp.cout_total = 32; rp.shuffle = 0; rp.scale = 1.f; rp.dw = dev_dw_oihw; rp.db = dev_db;
+            err = launch_wgrad_reduce(rp, s);
+        }
+    }
+    hipStreamSynchronize(s);
+    hipFree(fwd); hipFree(bwd);
+    if (err != hipSuccess) return fail(XSD_ERR_HIP, "bwd launch: %s", hipGetErrorString(err));
+    return XSD_OK;
+}
+
+} // extern "C"

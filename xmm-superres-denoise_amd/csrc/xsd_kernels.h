@@ -1,0 +1,120 @@
+// xsd_kernels.h -- device-side parameter blocks and host launch prototypes of the MI355X (gfx950) engine.
+//
+// All activations are "feature planes": fp32 NHWC tensors [B][H][W][32] (128 B per pixel = one full L2 line per
+// pixel per plane).  The reference's torch.cat over dense-block inputs (rrdb_blocks.py:49-52) never materialises:
+// a conv simply walks a LIST of planes, one 32-channel chunk per K-step.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xsd {
+
+constexpr int TILE_H = 8;          // output rows per workgroup
+constexpr int TILE_W = 32;         // output cols per workgroup (= MFMA M)
+constexpr int HALO_W = TILE_W + 2; // 34
+constexpr int HALO_H = TILE_H + 2; // 10
+constexpr int HALO_PX = HALO_W * HALO_H;        // 340
+constexpr int IN_LDS_BYTES = HALO_PX * 128;     // 43,520  (XOR-swizzled 16-B chunks, no padding)
+constexpr int PANEL_FLOATS = 9 * 32 * 32;       // 9,216 floats per (K-chunk x N-chunk) weight panel
+constexpr int W_LDS_BYTES = PANEL_FLOATS * 4;   // 36,864
+constexpr int CONV_LDS_BYTES = IN_LDS_BYTES + W_LDS_BYTES; // 80,384 -> 2 workgroups per CU (160 KiB LDS)
+
+// input plane reference with general strides (pixel-shuffled reads use rs = 2*Whr*32, ps = 64)
+struct PlaneIn {
+    const float* p;
+    long long bs; // batch stride (floats)
+    int rs;       // row stride (floats)
+    int ps;       // pixel stride (floats)
+};
+
+// One 32-channel output chunk and its fused epilogue:
+//   v = acc(+bias); v *= a1; if(accumulate) v += dst; if(e1) v += s1*e1; v *= a2; if(e2) v += s2*e2;
+//   if(e3) v += s3*e3; v = v>0 ? v : v*slope; if(mask) v = mask>0 ? v : v*mslope; dst = v
+// e1/e2/e3/mask are standard planes ([B][H][W][32] at the conv's own H,W).
+struct OutDesc {
+    float* p;
+    long long bs;
+    int rs, ps;
+    const float* e1;
+    const float* e2;
+    const float* e3;
+    const float* mask;
+    float a1, s1, a2, s2, s3, slope, mslope;
+    int accumulate;
+};
+
+struct ConvParams {
+    int B, H, W;
+    int n_in, n_out;     // (k,1): K-loop over input planes;  (1,k): one input tile, k output chunks
+    int tilesX, tilesY;
+    int std_rs;          // W*32
+    long long std_bs;    // H*W*32
+    PlaneIn in[5];
+    const float* wpanel; // [n_out][n_in] panels (one of the two is 1), PANEL_FLOATS each
+    const float* bias;   // [n_out*32] or nullptr
+    OutDesc out[5];
+};
+
+// weight-gradient kernel: dW_j[tap][ci][co] += sum_px X_j[px+tap][ci] * G[px][co]
+struct WgradParams {
+    int B, H, W;
+    int n_in;            // number of 32-channel input chunks X_j
+    int n_g;             // number of 32-channel G chunks (1, or 4 for the pixel-shuffle conv)
+    int tilesX, tilesY, nparts;
+    PlaneIn x[5];
+    PlaneIn g[4];
+    float* partial;      // [nparts][n_g][n_in][9][32 ci][32 co]
+    float* bias_partial; // [nparts][n_g][32]
+};
+
+struct WgradReduceParams {
+    const float* partial;
+    const float* bias_partial;
+    int nparts, n_in, n_g;
+    int cin_total, cout_total;
+    int shuffle;   // 1: output channel oc = 4*co + n (pixel-shuffle conv), else oc = 32*n + co
+    float scale;
+    float* dw;     // OIHW [cout_total][cin_total][3][3]
+    float* db;     // [cout_total]
+};
+
+// pack descriptor: one conv's OIHW weights -> forward and transposed (dgrad) panels
+struct PackDesc {
+    long long src_w;     // offset into flat params
+    long long dst_fwd;   // offset into packed fwd buffer
+    long long dst_bwd;   // offset into packed dgrad buffer
+    int cout, cin;       // multiples of 32
+    int shuffle;
+    int pad;
+};
+
+// edge layers (Cin=1 or Cout=1): HBM-bound VALU kernels
+struct EdgeExpandParams { // 1 -> 32 conv:  out[p][c] = bias[c] + sum_tap s[p+tap] * w[tap][c]; optional lrelu' mask
+    int B, H, W;
+    const float* s;      // [B][H][W]
+    const float* w;      // [9][32]
+    const float* bias;   // [32] or null
+    float* out;          // [B][H][W][32]
+    const float* mask;   // plane or null
+    float mslope;
+};
+struct EdgeReduceParams { // 32 -> 1 conv: pre[p] = bias + sum_tap sum_c f[p+tap][c] * w[tap][c] (+ skip[p]); y = clamp(pre)
+    int B, H, W;
+    const float* f;      // [B][H][W][32]
+    const float* w;      // [9][32]
+    const float* bias;   // [1] or null
+    const float* skip;   // [B][H][W] or null
+    float* pre;          // pre-clamp value (may be null)
+    float* y;            // output
+    int clamp01;
+    const float* addto;  // y = value + addto[p] (used for dx = dgrad + skip-grad), may be null
+};
+struct EdgeWgradParams { // out[tap][c] = sum_p f[p][c] * s[p+tap]; bsum[c] = sum_p f[p][c]; ssum = sum_p s[p]
+    int B, H, W;
+    const float* f;
+    const float* s;
+    float* partial;      // [nblocks][9*32 + 32 + 1]
+    int nblocks;
+};
+
+} // namespace xsd

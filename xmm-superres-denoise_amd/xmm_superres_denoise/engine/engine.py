@@ -1,0 +1,153 @@
+"""Thin host wrapper over the C ABI: torch supplies device memory and the HIP stream, nothing else."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import XsdConfig, XsdError, check
+
+STRETCH = {"linear": 0, "sqrt": 1, "asinh": 2, "log": 3}
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_cuda_f32(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise XsdError(f"{name} must be a CUDA(HIP) tensor: the MI355X engine has no CPU fallback (got {t.device})")
+    if t.dtype != torch.float32:
+        raise XsdError(f"{name} must be float32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise XsdError(f"{name} must be contiguous")
+
+
+class Engine:
+    """One engine per model instance per GPU (xsd_create / xsd_destroy)."""
+
+    def __init__(self, kind: str, in_channels: int, out_channels: int, num_filters: int, num_res_blocks: int,
+                 num_upsample: int = 1, memory_efficient: bool = False):
+        self.L = _lib.load()
+        cfg = XsdConfig(kind={"dn": 0, "sr": 1}[kind], in_channels=in_channels, out_channels=out_channels,
+                        num_filters=num_filters, num_res_blocks=num_res_blocks, num_upsample=num_upsample,
+                        memory_efficient=int(memory_efficient), reserved=0)
+        h = ctypes.c_void_p()
+        check(self.L.xsd_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self.h = h
+        self.kind = kind
+        self.scale = 2 ** num_upsample if kind == "sr" else 1
+        self.nparams = int(self.L.xsd_param_count(self.h))
+        self.num_stages = int(self.L.xsd_backward_num_stages(self.h))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.xsd_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- weights
+    def pack(self, flat_params: torch.Tensor):
+        _require_cuda_f32(flat_params, "flat_params")
+        if flat_params.numel() != self.nparams:
+            raise XsdError(f"flat_params has {flat_params.numel()} elements, engine expects {self.nparams}")
+        self._params_ref = flat_params  # keep alive: the engine reads biases from it
+        check(self.L.xsd_pack_weights(self.h, flat_params.data_ptr(), _stream_ptr(flat_params.device)))
+
+    # ---- forward / backward
+    def forward(self, x: torch.Tensor, save_for_backward: bool = False) -> torch.Tensor:
+        _require_cuda_f32(x, "x")
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise XsdError(f"x must be [B,1,H,W] (got {tuple(x.shape)})")
+        B, _, H, W = x.shape
+        y = torch.empty((B, 1, H * self.scale, W * self.scale), device=x.device, dtype=torch.float32)
+        check(self.L.xsd_forward(self.h, x.data_ptr(), y.data_ptr(), B, H, W, int(save_for_backward), _stream_ptr(x.device)))
+        self._x_ref = x if save_for_backward else None  # conv_first's weight gradient re-reads x
+        return y
+
+    def backward(self, dy: torch.Tensor, flat_grads: torch.Tensor, need_dx: bool = False):
+        _require_cuda_f32(dy, "dy")
+        _require_cuda_f32(flat_grads, "flat_grads")
+        dx = torch.empty_like(self._x_ref) if need_dx else None
+        check(self.L.xsd_backward(self.h, dy.data_ptr(), dx.data_ptr() if need_dx else None, flat_grads.data_ptr(),
+                                  _stream_ptr(dy.device)))
+        return dx
+
+    def backward_stage(self, stage: int, dy: torch.Tensor, flat_grads: torch.Tensor, dx: torch.Tensor | None = None):
+        check(self.L.xsd_backward_stage(self.h, stage, dy.data_ptr(), dx.data_ptr() if dx is not None else None,
+                                        flat_grads.data_ptr(), _stream_ptr(dy.device)))
+
+    def grad_range(self, stage: int):
+        off, cnt = ctypes.c_int64(), ctypes.c_int64()
+        self.L.xsd_grad_range(self.h, stage, 0, ctypes.byref(off), ctypes.byref(cnt))
+        return off.value, cnt.value
+
+    # ---- loss / optimizer
+    def l1_loss(self, y: torch.Tensor, target: torch.Tensor, want_grad: bool = True):
+        _require_cuda_f32(y, "y")
+        _require_cuda_f32(target, "target")
+        if y.shape != target.shape:
+            raise XsdError(f"shape mismatch {tuple(y.shape)} vs {tuple(target.shape)}")
+        dy = torch.empty_like(y) if want_grad else None
+        loss = torch.empty((), device=y.device, dtype=torch.float32)
+        check(self.L.xsd_l1_loss(self.h, y.data_ptr(), target.data_ptr(), dy.data_ptr() if want_grad else None,
+                                 loss.data_ptr(), y.numel(), _stream_ptr(y.device)))
+        return loss, dy
+
+    def adam_step(self, params, grads, m, v, step, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        for n, t in (("params", params), ("grads", grads), ("m", m), ("v", v)):
+            _require_cuda_f32(t, n)
+        check(self.L.xsd_adam_step(self.h, params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                   params.numel(), int(step), lr, betas[0], betas[1], eps, grad_scale,
+                                   _stream_ptr(params.device)))
+
+    # ---- measurement
+    def profile_enable(self, on: bool):
+        check(self.L.xsd_profile_enable(self.h, int(on)))
+
+    def profile_read(self, klass: int):
+        ms, n, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        check(self.L.xsd_profile_read(self.h, klass, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by)))
+        return {"ms": ms.value, "launches": n.value, "flop": fl.value, "bytes": by.value}
+
+
+# ---- stateless transform entry points --------------------------------------------------------------------------
+def mask_pad_normalize(counts: torch.Tensor, mask: torch.Tensor | None, res: int, max_val: float | None,
+                       stretch: str = "linear") -> torch.Tensor:
+    """counts [B,Hin,Win] int32|float32 (CUDA), mask [Hin,Win] uint8 -> [B,1,res,res] float32."""
+    L = _lib.load()
+    if not counts.is_cuda:
+        raise XsdError("counts must be a CUDA(HIP) tensor: no CPU fallback")
+    if counts.dtype not in (torch.int32, torch.float32) or not counts.is_contiguous():
+        raise XsdError("counts must be contiguous int32 or float32")
+    if mask is not None and (mask.dtype != torch.uint8 or not mask.is_cuda or tuple(mask.shape) != tuple(counts.shape[-2:])):
+        raise XsdError("mask must be a CUDA uint8 tensor [Hin,Win]")
+    B, Hin, Win = counts.shape
+    out = torch.empty((B, 1, res, res), device=counts.device, dtype=torch.float32)
+    check(L.xsd_mask_pad_normalize(counts.data_ptr(), int(counts.dtype == torch.int32),
+                                   mask.data_ptr() if mask is not None else None, out.data_ptr(), B, Hin, Win, res,
+                                   int(max_val is not None), float(max_val or 0.0), STRETCH[stretch],
+                                   _stream_ptr(counts.device)))
+    return out
+
+
+def normalize(img: torch.Tensor, max_val: float, stretch: str, inverse: bool = False) -> torch.Tensor:
+    L = _lib.load()
+    _require_cuda_f32(img, "img")
+    out = torch.empty_like(img)
+    check(L.xsd_normalize(img.data_ptr(), out.data_ptr(), img.numel(), float(max_val), STRETCH[stretch], int(inverse),
+                          _stream_ptr(img.device)))
+    return out
+
+
+def image_upsample(x: torch.Tensor, scale: int) -> torch.Tensor:
+    L = _lib.load()
+    _require_cuda_f32(x, "x")
+    H, W = x.shape[-2:]
+    n = x.numel() // (H * W)
+    out = torch.empty(tuple(x.shape[:-2]) + (H * scale, W * scale), device=x.device, dtype=torch.float32)
+    check(L.xsd_image_upsample(x.data_ptr(), out.data_ptr(), n, H, W, scale, _stream_ptr(x.device)))
+    return out

@@ -1,0 +1,76 @@
+"""`Model`: the reference's LightningModule (models/model.py:13-247) restated without Lightning for the RRDB paths:
+constructor signature, `configure_model` factory (model.py:153-186), `forward` = clamp(generator(x), 0, 1)
+(model.py:48-49 -- the second clamp is fused in the engine's output kernel and is idempotent), the train branch of
+`_on_step` (model.py:72-86) and `configure_optimizers` (model.py:239-247).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from xmm_superres_denoise.config.config import BaseModels, ModelCfg
+
+
+class Model(nn.Module):
+    def __init__(self, config: ModelCfg, lr_shape: Tuple[int, int], hr_shape: Tuple[int, int], loss=None,
+                 metrics=None, extended_metrics=None, in_metrics=None, in_extended_metrics=None):
+        super().__init__()
+        self.config = config
+        self.metrics = metrics
+        self.ext_metrics = extended_metrics
+        self.in_metrics = in_metrics
+        self.in_ext_metrics = in_extended_metrics
+        self.loss = loss
+        self.model: Optional[nn.Module] = None
+        self.hr_shape = hr_shape
+        self.lr_shape = lr_shape
+
+    def forward(self, x) -> torch.Tensor:
+        if self.model is None:
+            self.configure_model()
+        # the generator already returns clamp(clamp(.)) == clamp(.)
+        return self.model(x)
+
+    def configure_model(self) -> None:
+        if self.model is not None:
+            return
+        from xmm_superres_denoise.models import GeneratorRRDB_DN, GeneratorRRDB_SR
+        name = BaseModels(self.config.name)
+        if name is BaseModels.ESR_GEN:
+            up_scale = self.hr_shape[0] / self.lr_shape[0]
+            if up_scale % 2 != 0:
+                raise ValueError(f"Upscaling is not a multiple of two but {up_scale}, "
+                                 f"based on in_dims {self.lr_shape} and out_dims {self.hr_shape}")
+            self.model = GeneratorRRDB_SR(in_channels=self.config.model.in_channels,
+                                          out_channels=self.config.model.out_channels,
+                                          num_filters=self.config.model.filters,
+                                          num_res_blocks=self.config.model.residual_blocks,
+                                          num_upsample=int(up_scale / 2),
+                                          memory_efficient=self.config.memory_efficient)
+        elif name is BaseModels.RRDB_DENOISE:
+            self.model = GeneratorRRDB_DN(in_channels=self.config.model.in_channels,
+                                          out_channels=self.config.model.out_channels,
+                                          num_filters=self.config.model.filters,
+                                          num_res_blocks=self.config.model.residual_blocks,
+                                          memory_efficient=self.config.memory_efficient)
+        else:
+            raise NotImplementedError(f"{name}: only the RRDB generators are on the MI355X hot path (SURVEY.md section 8)")
+
+    def training_step(self, batch, batch_idx=0):
+        return self._on_step(batch, "train")
+
+    def _on_step(self, batch, stage):
+        lr_img, hr_img = batch
+        preds = self(lr_img)
+        target = hr_img if hr_img is not None else preds
+        if stage == "train":
+            return self.loss(preds, target)
+        return preds
+
+    def configure_optimizers(self):
+        if self.model is None:
+            self.configure_model()
+        return torch.optim.Adam(self.model.parameters(), lr=self.config.optimizer.learning_rate,
+                                betas=tuple(self.config.optimizer.betas))

@@ -1,0 +1,151 @@
+"""GeneratorRRDB_SR / GeneratorRRDB_DN with the reference constructor signatures and state_dict keys
+(reference models/modules/generator_rrdb.py:9-64,72-101,113-121), computing through the MI355X engine.
+
+forward(x[B,1,H,W] fp32, CUDA) -> clamp(...)[B,1,sH,sW]   (reference :103-110, :130-137)
+Autograd is supplied by one torch.autograd.Function spanning the whole network: backward calls xsd_backward,
+which returns dL/dx and every parameter gradient in one flat buffer laid out like the flat parameter buffer.
+"""
+from __future__ import annotations
+
+import functools
+import math
+
+import torch
+from torch import nn
+
+from xmm_superres_denoise.engine import Engine, XsdError
+
+from .rrdb_blocks import RRDB, make_layer
+
+
+class _EngineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, need, x, *params):
+        eng = module._get_engine(x.device)
+        eng.pack(module._flat)
+        y = eng.forward(x.contiguous(), save_for_backward=need)
+        ctx.module = module
+        ctx.need_dx = x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        m = ctx.module
+        eng = m._engine
+        grads = torch.empty_like(m._flat)
+        dx = eng.backward(dy.contiguous(), grads, need_dx=ctx.need_dx)
+        outs, off = [], 0
+        for p in m._plist:
+            n = p.numel()
+            outs.append(grads[off:off + n].view_as(p) if p.requires_grad else None)
+            off += n
+        return (None, None, dx, *outs)
+
+
+class _GeneratorRRDB(nn.Module):
+    _kind = None
+
+    def __init__(self, in_channels: int, out_channels: int, num_filters: int, num_res_blocks: int,
+                 memory_efficient: bool = False):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.num_filters = num_filters
+        self.num_res_blocks = num_res_blocks
+        self.memory_efficient = memory_efficient
+        # same construction order as the reference => same default init under the same torch seed
+        rrdb = functools.partial(RRDB, nf=num_filters, gc=num_filters, memory_efficient=memory_efficient)
+        self.conv_first = nn.Conv2d(in_channels, num_filters, 3, 1, 1)
+        self.rrdb = make_layer(rrdb, num_res_blocks)
+        self.trunk_conv = nn.Conv2d(num_filters, num_filters, 3, 1, 1)
+        self.conv_last = nn.Conv2d(num_filters, out_channels, 3, 1, 1)
+        # positive-biased init of conv_last (reference generator_rrdb.py:56-64)
+        positive_offset_std = 0.01
+        stdv = 1.0 / math.sqrt(self.conv_last.weight.size(1))
+        self.conv_last.weight.data.uniform_(-stdv, stdv + positive_offset_std * stdv)
+        if self.conv_last.bias is not None:
+            self.conv_last.bias.data.uniform_(-stdv, stdv + positive_offset_std * stdv)
+        self._engine = None
+        self._engine_dev = None
+        self._flat = None
+        self._plist = None
+
+    # ---- flat parameter buffer ---------------------------------------------------------------------------------
+    def _num_upsample(self):
+        return 1
+
+    def flatten_parameters(self):
+        """Make every parameter a view into ONE contiguous fp32 buffer in state_dict order (the engine's flat-params
+        layout, include/xsd.h).  Re-run automatically after .to()/.cuda() moved the parameters."""
+        plist = list(self.parameters())
+        dev = plist[0].device
+        ok = self._flat is not None and self._flat.device == dev
+        if ok:
+            off = 0
+            base = self._flat.data_ptr()
+            for p in plist:
+                if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+                    ok = False
+                    break
+                off += p.numel()
+        if not ok:
+            flat = torch.empty(sum(p.numel() for p in plist), dtype=torch.float32, device=dev)
+            off = 0
+            for p in plist:
+                n = p.numel()
+                flat[off:off + n].copy_(p.data.reshape(-1).float())
+                p.data = flat[off:off + n].view(p.shape)
+                off += n
+            self._flat = flat
+        self._plist = plist
+        return self._flat
+
+    def flat_parameters(self) -> torch.Tensor:
+        return self.flatten_parameters()
+
+    def _get_engine(self, device):
+        if not torch.device(device).type == "cuda":
+            raise XsdError("the MI355X engine needs CUDA(HIP) tensors; there is no CPU fallback")
+        flat = self.flatten_parameters()
+        if flat.device != torch.device(device):
+            raise XsdError(f"module parameters are on {flat.device} but the input is on {device}")
+        if self._engine is None or self._engine_dev != flat.device:
+            with torch.cuda.device(flat.device):
+                self._engine = Engine(self._kind, self.in_channels, self.out_channels, self.num_filters,
+                                      self.num_res_blocks, self._num_upsample(), self.memory_efficient)
+            self._engine_dev = flat.device
+        return self._engine
+
+    def forward(self, x):
+        if x.dtype != torch.float32:
+            raise XsdError(f"input must be float32 (got {x.dtype})")
+        self._get_engine(x.device)
+        # grad mode is off inside autograd.Function.forward, so decide here whether activations must be kept
+        need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self._plist))
+        return _EngineFn.apply(self, need, x, *self._plist)
+
+
+class GeneratorRRDB_SR(_GeneratorRRDB):
+    _kind = "sr"
+
+    def __init__(self, in_channels: int, out_channels: int, num_filters: int, num_res_blocks: int,
+                 num_upsample: int = 2, memory_efficient: bool = False):
+        super().__init__(in_channels=in_channels, out_channels=out_channels, num_filters=num_filters,
+                         num_res_blocks=num_res_blocks, memory_efficient=memory_efficient)
+        self.num_upsample = num_upsample
+        layers = []
+        for _ in range(num_upsample):  # reference generator_rrdb.py:91-99
+            layers += [nn.Conv2d(num_filters, num_filters * 4, 3, 1, 1), nn.LeakyReLU(inplace=True), nn.PixelShuffle(2)]
+        self.upsampling = nn.Sequential(*layers)
+        self.HRconv = nn.Conv2d(num_filters, num_filters, 3, 1, 1, bias=True)
+
+    def _num_upsample(self):
+        return self.num_upsample
+
+
+class GeneratorRRDB_DN(_GeneratorRRDB):
+    _kind = "dn"
+
+    def __init__(self, in_channels, out_channels, num_filters, num_res_blocks, memory_efficient=False):
+        super().__init__(in_channels=in_channels, out_channels=out_channels, num_filters=num_filters,
+                         num_res_blocks=num_res_blocks, memory_efficient=memory_efficient)
