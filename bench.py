@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: XMM 512x512 tiles/sec for a train step.
+
+A "step" = one pass of the hot path over one batch of synthetic tiles (x ~ U[0,1) seed 0, target ~ U[0,1) seed 1,
+reference-default weight init under torch.manual_seed(0)):
+    weight repack -> forward (activations kept) -> mean-L1 loss -> backward (input + weight gradients)
+    -> [RCCL all-reduce of the flat gradient, overlapped with backward, when N > 1] -> fused Adam.
+Default workload at N=1: BASELINE configs[2] "XMM-DeNoise train step, batch 32, 1 MI355X, fwd+bwd HIP kernels".
+At N>1 each rank keeps 16 tiles (configs[3]/[4]: 64 over 4, 128 over 8), weak scaling, one process per GPU.
+Other workloads (parity-test configs, not bench lines): --workload sr_fwd (configs[1]), sr_train, dn_fwd.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     : dominant kernel (conv3x3_mfma) algorithmic FLOP / HIP-event time inside the timed region vs the fp32
+                 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md), and
+  cpu_baseline : the same train step (B=1) through oracle/oracle.py's torch restatement on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "xmm-superres-denoise_amd"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3
+TILE = 512
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: min(affinity, cgroup cpu.max quota, 16 = a 1-GPU box's CPU share)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(kind: str, train: bool):
+    """Reference op graph on the host CPU (torch restatement, pinned to the reference by tests/test_oracle_pinned.py):
+    one B=1 512x512 step, all host cores."""
+    from oracle import oracle
+    from xmm_superres_denoise.models import GeneratorRRDB_DN, GeneratorRRDB_SR
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m = GeneratorRRDB_DN(1, 1, 32, 4) if kind == "dn" else GeneratorRRDB_SR(1, 1, 32, 4, num_upsample=1)
+    state = {k: v.detach().clone().requires_grad_(train) for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand((1, 1, TILE, TILE), generator=g)
+    s = 2 if kind == "sr" else 1
+    t = torch.rand((1, 1, TILE * s, TILE * s), generator=torch.Generator().manual_seed(1))
+    opt = torch.optim.Adam(list(state.values()), lr=1e-4, betas=(0.9, 0.999)) if train else None
+    # warm-up on a small tile (thread pool / oneDNN primitive creation), then ONE timed full-size step
+    with torch.set_grad_enabled(train):
+        oracle.torch_forward(kind, 32, 4, state, x[..., :64, :64])
+    t0 = time.perf_counter()
+    if train:
+        y = oracle.torch_forward(kind, 32, 4, state, x)
+        loss = torch.nn.functional.l1_loss(y, t)
+        loss.backward()
+        opt.step()
+    else:
+        with torch.no_grad():
+            oracle.torch_forward(kind, 32, 4, state, x)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"1 {'train step (fwd+L1+bwd+Adam)' if train else 'forward'} of 1 tile 1x{TILE}x{TILE}, torch-CPU "
+                      f"restatement of the reference graph (oracle/oracle.py:torch_forward), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="dn_train", choices=["dn_train", "sr_train", "dn_fwd", "sr_fwd"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 32 at N=1, 16 at N>1; sr_fwd: 16)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus} (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from xmm_superres_denoise.models import GeneratorRRDB_DN, GeneratorRRDB_SR
+    from xmm_superres_denoise.parallel import DataParallelTrainer
+
+    kind, mode = args.workload.split("_")
+    train = mode == "train"
+    B = args.batch or (16 if (world > 1 or args.workload == "sr_fwd") else 32)
+    scale = 2 if kind == "sr" else 1
+
+    torch.manual_seed(0)  # same seeded default init on every rank (DP replicas start identical)
+    model = (GeneratorRRDB_DN(1, 1, 32, 4) if kind == "dn" else GeneratorRRDB_SR(1, 1, 32, 4, num_upsample=1)).to(dev)
+    # synthetic data: global batch generated from one seed, each rank takes its shard (DistributedSampler analogue)
+    gx = torch.Generator().manual_seed(0)
+    gt = torch.Generator().manual_seed(1)
+    x = torch.rand((B * world, 1, TILE, TILE), generator=gx)[rank * B:(rank + 1) * B].contiguous().to(dev)
+    tgt = None
+    if train:
+        tgt = torch.rand((B * world, 1, TILE * scale, TILE * scale), generator=gt)[rank * B:(rank + 1) * B].contiguous().to(dev)
+
+    trainer = DataParallelTrainer(model, lr=1e-4, betas=(0.9, 0.999))
+    eng = trainer.engine
+
+    def step():
+        if train:
+            return trainer.train_step(x, tgt)
+        with torch.no_grad():
+            return model(x)
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_profile:
+        eng.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    prof = None
+    if not args.no_profile:
+        prof = {0: eng.profile_read(0), 1: eng.profile_read(1)}
+        eng.profile_enable(False)
+
+    if rank == 0:
+        tiles = B * world * args.steps
+        out = {
+            "metric": "XMM 512x512 tiles/sec (train step)" if train else "XMM 512x512 tiles/sec (forward)",
+            "value": tiles / dt, "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": {"dn_train": "XMM-DeNoise train step (L1 + Adam), fwd+bwd HIP kernels",
+                                    "sr_train": "XMM-SuperRes 2x train step (L1 + Adam)",
+                                    "dn_fwd": "XMM-DeNoise forward", "sr_fwd": "XMM-SuperRes 2x generator forward"}[args.workload],
+                       "tile": f"1x{TILE}x{TILE}", "per_gpu_batch": B, "global_batch": B * world,
+                       "net": "RRDB nf=32 x 4 blocks", "parallelism": f"dp{world}"},
+        }
+        if prof is not None and prof[0]["launches"] > 0:
+            k = prof[0]
+            ach = k["flop"] / (k["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "launches": k["launches"], "avg_launch_ms": k["ms"] / k["launches"],
+                               "algorithmic_GBps": k["bytes"] / (k["ms"] * 1e-3) / 1e9}
+            if prof[1]["launches"] > 0:
+                w = prof[1]
+                out["roofline"]["wgrad_mfma_kernel"] = {"achieved": w["flop"] / (w["ms"] * 1e-3) / 1e12,
+                                                        "frac": w["flop"] / (w["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                                        "launches": w["launches"], "avg_launch_ms": w["ms"] / w["launches"]}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kind, train)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -172,8 +172,18 @@ __global__ void wgrad_reduce_kernel(const WgradReduceParams R)
         const int j = r % R.n_in;
         const int n = r / R.n_in;
         const long long stride = (long long)R.n_g * R.n_in * 9 * 1024;
-        double s = 0.0;
-        for (int p = 0; p < R.nparts; ++p) s += (double)R.partial[p * stride + e];
+        // fixed summation order (4 interleaved chains, then a fixed combine) with 8 loads in flight
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int p = 0;
+        for (; p + 8 <= R.nparts; p += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = R.partial[(p + u) * stride + e];
+            s0 += (double)v[0] + (double)v[4]; s1 += (double)v[1] + (double)v[5];
+            s2 += (double)v[2] + (double)v[6]; s3 += (double)v[3] + (double)v[7];
+        }
+        for (; p < R.nparts; ++p) s0 += (double)R.partial[p * stride + e];
+        const double s = (s0 + s1) + (s2 + s3);
         const int oc = R.shuffle ? (4 * co + n) : (32 * n + co);
         R.dw[((long long)oc * R.cin_total + (32 * j + ci)) * 9 + tap] = (float)(s * (double)R.scale);
     }
