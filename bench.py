@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="dn_train", choices=["dn_train", "sr_train", "dn_fwd", "sr_fwd"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 32 at N=1, 16 at N>1; sr_fwd: 16)")
+    ap.add_argument("--math", default=os.environ.get("XSD_MATH", "fp32"), choices=["fp32", "bf16x3"],
+                    help="MFMA math mode of the conv kernels (include/xsd.h: xsd_set_math)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -122,6 +124,7 @@ def main():
     if train:
         tgt = torch.rand((B * world, 1, TILE * scale, TILE * scale), generator=gt)[rank * B:(rank + 1) * B].contiguous().to(dev)
 
+    model.set_math(args.math)
     trainer = DataParallelTrainer(model, lr=1e-4, betas=(0.9, 0.999))
     eng = trainer.engine
 
@@ -166,7 +169,7 @@ def main():
                                     "sr_train": "XMM-SuperRes 2x train step (L1 + Adam)",
                                     "dn_fwd": "XMM-DeNoise forward", "sr_fwd": "XMM-SuperRes 2x generator forward"}[args.workload],
                        "tile": f"1x{TILE}x{TILE}", "per_gpu_batch": B, "global_batch": B * world,
-                       "net": "RRDB nf=32 x 4 blocks", "parallelism": f"dp{world}"},
+                       "net": "RRDB nf=32 x 4 blocks", "math": args.math, "parallelism": f"dp{world}"},
         }
         if prof is not None and prof[0]["launches"] > 0:
             k = prof[0]

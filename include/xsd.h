@@ -56,6 +56,13 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out);
 void xsd_destroy(xsd_engine* e);
 int64_t xsd_param_count(const xsd_engine* e);
 
+/* Math mode of the MFMA convs (forward + input-gradient): 0 = exact fp32 (v_mfma_f32_32x32x2_f32);
+ * 1 = "bf16x3": operands split into hi+lo bf16 terms, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation (per-product error <= 3*2^-16; whole-net error ~5e-6 of max, inside the 1e-3 parity tolerance).
+ * Default from the environment variable XSD_MATH ("fp32" | "bf16x3").  Changing it invalidates the packed weights. */
+int xsd_set_math(xsd_engine* e, int mode);
+int xsd_get_math(const xsd_engine* e);
+
 /* Repack the caller's flat OIHW parameters into MFMA fragment-order panels (forward + transposed/flipped for the
  * input-gradient).  Must be called after every parameter update and before forward.  Replaces nothing in the
  * reference (torch reads OIHW directly); it is the engine's weight-layout step. */
@@ -105,6 +112,10 @@ int xsd_image_upsample(const float* dev_in, float* dev_out, int N, int H, int W,
  * class 0 = conv3x3_mfma (forward + input-gradient), 1 = wgrad_mfma.  enable resets the counters. */
 int xsd_profile_enable(xsd_engine* e, int enable);
 int xsd_profile_read(xsd_engine* e, int klass, double* total_ms, int64_t* launches, double* total_flop, double* total_bytes);
+
+/* Diagnostic only: accumulated shader-cycle stamps of the conv kernel's phases
+ * [0] prologue, [1] prefetch issue, [2] MFMA loop, [3] epilogue, [4] wait+barrier, [5] split+LDS write+barrier, [6] items. */
+int xsd_debug_stamps(xsd_engine* e, int enable, unsigned long long* out8);
 
 /* Single-layer entry points used by the kernel-level parity tests (one 3x3 conv over NHWC 32-channel planes).
  * dev_in: [n_in] plane pointers on the host (each plane [B][H][W][32]); w_oihw: device OIHW [32*n_out][32*n_in][3][3]. */

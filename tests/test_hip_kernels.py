@@ -13,10 +13,13 @@ from util_hip import nchw_to_planes, planes_to_nchw, ptr_array
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=["fp32", "bf16x3"])
+def eng(request):
     from xmm_superres_denoise.engine import Engine
-    return Engine("dn", 1, 1, 32, 1)
+    e = Engine("dn", 1, 1, 32, 1)
+    e.set_math(request.param)
+    e.tol = {"fp32": 2e-5, "bf16x3": 6e-5}[request.param]   # bf16x3: <= 3*2^-16 per product, random-sign sums
+    return e
 
 
 def _rel(a, b):
@@ -43,7 +46,7 @@ def test_conv3x3_forward(eng, n_in, n_out, shape):
                                  0.2, B, H, W, None))
     got = planes_to_nchw(outs)
     assert np.isfinite(got).all()
-    assert _rel(got, ref) < 2e-5
+    assert _rel(got, ref) < eng.tol
 
 
 @pytest.mark.parametrize("n_in,shape", [(1, (1, 8, 32)), (2, (2, 19, 45)), (3, (1, 40, 33)), (5, (2, 17, 70))])
@@ -63,7 +66,7 @@ def test_conv3x3_backward(eng, n_in, shape):
     db = torch.full((32,), float("nan"), device="cuda")
     check(eng.L.xsd_test_conv3x3_bwd(eng.h, ptr_array(xin), n_in, wd.data_ptr(), gp.data_ptr(), ptr_array(dxs),
                                      dw.data_ptr(), db.data_ptr(), B, H, W, None))
-    assert _rel(planes_to_nchw(dxs), dx_ref) < 2e-5
+    assert _rel(planes_to_nchw(dxs), dx_ref) < eng.tol
     assert _rel(dw.cpu().numpy(), dw_ref) < 5e-5
     assert _rel(db.cpu().numpy(), db_ref) < 5e-5
 

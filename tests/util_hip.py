@@ -47,3 +47,25 @@ def ptr_array(tensors):
     for i, t in enumerate(tensors):
         arr[i] = t.data_ptr()
     return arr
+
+
+def assert_grad_close(g, ref, name, tight=2e-4, loose=2e-2, max_flip_frac=0.15):
+    """Gradient comparison that is robust to the network's genuine discontinuities.
+
+    LeakyReLU', the clamp mask and sign(y - t) are step functions: an activation within ~1e-6 of zero can take a
+    different branch in two fp32-accurate implementations, which changes ONE (pixel, channel) term and therefore one
+    output-channel row of one conv's dW/db by O(1/sqrt(N)), plus a tiny ripple upstream.  So: either every element
+    agrees to `tight` (relative to the tensor's max), or at most `max_flip_frac` of the leading-dimension rows exceed
+    `tight`, nothing exceeds `loose`, and the relative L2 error stays below `loose`/2."""
+    g = np.asarray(g, np.float64).reshape(ref.shape)
+    r = np.asarray(ref, np.float64)
+    scale = np.abs(r).max() + 1e-30
+    err = np.abs(g - r) / scale
+    if err.max() <= tight:
+        return
+    rows = err.reshape(err.shape[0], -1).max(axis=1) if err.ndim > 1 else err
+    nbad = int((rows > tight).sum())
+    assert err.max() <= loose, f"{name}: max rel err {err.max():.3e} > loose {loose}"
+    assert nbad <= max(1, int(max_flip_frac * rows.size)), f"{name}: {nbad}/{rows.size} rows exceed {tight}"
+    l2 = np.linalg.norm(g - r) / (np.linalg.norm(r) + 1e-30)
+    assert l2 <= loose / 2, f"{name}: rel L2 {l2:.3e}"

@@ -256,6 +256,43 @@ __global__ void pack_weights_kernel(const float* params, const PackDesc* descs, 
     }
 }
 
+// bf16x3 panels (conv3x3_mfma_kernel<*, SPLIT=true>): 16-bit elements [tap][s2][hi|lo][lane = h*32 + c][j], the k index
+// of element j is 16*s2 + 8*h + j; forward/dgrad channel maps as in pack_weights_kernel.  Same byte size per panel.
+__global__ void pack_weights_split_kernel(const float* params, const PackDesc* descs, unsigned short* fwd, unsigned short* bwd)
+{
+    const PackDesc d = descs[blockIdx.y];
+    const int ns = d.cin / 32, nn = d.cout / 32;
+    const int PE = 2 * PANEL_FLOATS; // 18,432 16-bit elements per panel
+    const long long total = (long long)ns * nn * PE;
+    const float* W = params + d.src_w;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        int r = (int)(e % PE);
+        const int panel = (int)(e / PE);
+        const int j = r & 7; r >>= 3;
+        const int c = r & 31; r >>= 5;
+        const int h = r & 1; r >>= 1;
+        const int part = r & 1; r >>= 1;
+        const int s2 = r & 1; r >>= 1;
+        const int tap = r;
+        const int k = 16 * s2 + 8 * h + j;
+        float wf, wb;
+        {
+            const int n = panel / ns, s = panel % ns;
+            const int oc = d.shuffle ? (4 * c + n) : (32 * n + c);
+            wf = W[((long long)oc * d.cin + 32 * s + k) * 9 + tap];
+        }
+        {
+            const int s = panel / nn, n = panel % nn;
+            const int oc = d.shuffle ? (4 * k + n) : (32 * n + k);
+            wb = W[((long long)oc * d.cin + 32 * s + c) * 9 + (8 - tap)];
+        }
+        const __bf16 fh = (__bf16)wf, bh = (__bf16)wb;
+        const __bf16 fl = (__bf16)(wf - (float)fh), bl = (__bf16)(wb - (float)bh);
+        fwd[2 * d.dst_fwd + e] = __builtin_bit_cast(unsigned short, part ? fl : fh);
+        bwd[2 * d.dst_bwd + e] = __builtin_bit_cast(unsigned short, part ? bl : bh);
+    }
+}
+
 // edge-layer weights: conv_first W[c][0][tap] -> [tap][c] (forward) ; conv_last W[0][c][tap] -> [tap][c] (forward)
 // and the flipped forms used by their input-gradients.
 __global__ void pack_edge_kernel(const float* w_first, const float* w_last, float* first_fwd, float* first_bwd,
@@ -408,6 +445,12 @@ hipError_t launch_pack_weights(const float* params, const PackDesc* descs_dev, i
                                hipStream_t s)
 {
     hipLaunchKernelGGL(pack_weights_kernel, dim3(36, ndesc), dim3(256), 0, s, params, descs_dev, fwd, bwd);
+    return hipGetLastError();
+}
+hipError_t launch_pack_weights_split(const float* params, const PackDesc* descs_dev, int ndesc, unsigned short* fwd,
+                                     unsigned short* bwd, hipStream_t s)
+{
+    hipLaunchKernelGGL(pack_weights_split_kernel, dim3(72, ndesc), dim3(256), 0, s, params, descs_dev, fwd, bwd);
     return hipGetLastError();
 }
 hipError_t launch_pack_edge(const float* w_first, const float* w_last, float* ff, float* fb, float* lf, float* lb,

@@ -13,6 +13,15 @@
 // K-steps are software pipelined through registers (issue the next plane's global loads before the MFMAs of the
 // current one, write LDS after the barrier); the second co-resident workgroup covers the short write phase.
 //
+// Two math modes share the structure (template parameter SPLIT):
+//   SPLIT=false : exact fp32, v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD = the fp32 vector rate).
+//   SPLIT=true  : "bf16x3": each fp32 operand is split x = hi + lo (two bf16, 16 significant bits) and the product is
+//                 evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 3 MFMAs at 16x
+//                 the fp32 rate = 5.3x the fp32-MFMA ceiling, per-product error <= 3*2^-16 (measured whole-net error
+//                 5e-6 of max vs the reference, tolerance 1e-3).  Activations stay fp32 in HBM; the split happens once
+//                 per staged element on the way into LDS (pixel row = [32 x hi][32 x lo] bf16 = the same 128 B);
+//                 weights are pre-split by pack_weights_split_kernel into [tap][kstep][hi|lo][lane][8] fragments.
+//
 // Two step structures share the code:
 //   MULTI_OUT=false : n_in input planes (K-loop), one output chunk          (forward dense convs; dgrad of 32->128)
 //   MULTI_OUT=true  : one input plane staged once, n_out output chunks      (dgrad of dense convs; forward 32->128)
@@ -22,22 +31,38 @@ namespace xsd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int IN_SLOTS = HALO_PX * 8;              // 2720 16-byte chunks
 constexpr int IN_ROUNDS = (IN_SLOTS + 255) / 256;  // 11
 constexpr int W_ROUNDS = PANEL_FLOATS / 4 / 256;   // 9
+constexpr int SP_SLOTS = HALO_PX * 4;              // split mode: 1360 (pixel, 8-channel octet) slots of 32 B
+constexpr int SP_ROUNDS = (SP_SLOTS + 255) / 256;  // 6
 
-__device__ __forceinline__ int swz_off(int p, int c) { return p * 128 + ((c ^ ((p >> 1) & 7)) << 4); }
-
-// bijective XCD-aware remap: workgroups that share an XCD (bid % 8) get a contiguous range of tiles, so halo rows and
-// the weight panels are re-read from that XCD's own L2.
-__device__ __forceinline__ int xcd_remap(int bid, int n)
+// fp32 -> (hi, lo) bf16 pair, round-to-nearest-even on both terms
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u16x8& hi, u16x8& lo)
 {
-    const int q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float x = i < 4 ? a[i] : b[i - 4];
+        const __bf16 h = (__bf16)x;
+        const float hf = (float)h;
+        const __bf16 l = (__bf16)(x - hf);
+        hi[i] = __builtin_bit_cast(unsigned short, h);
+        lo[i] = __builtin_bit_cast(unsigned short, l);
+    }
 }
 
-template <bool MULTI_OUT>
+constexpr int ROW_BYTES = HALO_W * 128; // 4352 = 17 x 256: every halo row starts on a bank-row boundary
+
+// LDS byte offset of 16-B chunk c (0..7) of halo pixel (hy, hx).  The XOR swizzle depends on hx only, so a tap shift
+// (dy, dx) is "+ dy*ROW_BYTES" (an instruction immediate) on top of one of three per-lane bases (dx = 0,1,2):
+// no address arithmetic is left in the MFMA loop.  A ds_read_b128 lane group (16 lanes = 16 consecutive hx, same c)
+// touches 16 distinct 16-B slots of the 256-B bank row -> conflict-free.
+__device__ __forceinline__ int swz_off(int hy, int hx, int c) { return hy * ROW_BYTES + hx * 128 + ((c ^ ((hx >> 1) & 7)) << 4); }
+
+template <bool MULTI_OUT, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -51,38 +76,97 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
     const int l31 = lane & 31;
 
     const int ntiles = P.B * P.tilesY * P.tilesX;
-    int t = xcd_remap(blockIdx.x, ntiles);
-    const int tx = t % P.tilesX; t /= P.tilesX;
-    const int ty = t % P.tilesY;
-    const int b = t / P.tilesY;
-    const int x0 = tx * TILE_W, y0 = ty * TILE_H;
-
     const int nsteps = MULTI_OUT ? P.n_out : P.n_in;
+    // persistent: workgroup g walks tiles g, g + G, g + 2G, ... and software-pipelines across tile boundaries
+    const int G = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    const int items = my_tiles * nsteps;
 
-    f32x4 pin[IN_ROUNDS];
+    struct TileXY { int b, y0, x0; };
+    auto tile_of = [&](int k) {
+        int t = (int)blockIdx.x + k * G;
+        TileXY r;
+        const int tx = t % P.tilesX; t /= P.tilesX;
+        r.x0 = tx * TILE_W; r.y0 = (t % P.tilesY) * TILE_H; r.b = t / P.tilesY;
+        return r;
+    };
+
+    // per-lane LDS read bases: [dx][k], k = the 4 A-fragment chunks of one (row, tap)
+    int abase[3][4];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = SPLIT ? ((k >> 1) * 4 + 2 * (k & 1) + h) : (4 * h + k); // split: k = part*2 + s2
+            abase[dx][k] = swz_off(wv * 2, l31 + dx, c);
+        }
+
+    f32x4 pin[SPLIT ? 2 * SP_ROUNDS : IN_ROUNDS];
     f32x4 pw[W_ROUNDS];
 
-    auto load_in = [&](int s) {
-        const PlaneIn pl = P.in[s];
-        const float* base = pl.p + (long long)b * pl.bs;
+    // per-thread element offsets of this thread's staging slots inside one image of the current/next tile
+    // (-1 = zero padding / out of range); identical for every plane of the tile, so computed once per tile.
+    constexpr int NR = SPLIT ? SP_ROUNDS : IN_ROUNDS;
+    auto slot_offset = [&](int r, const TileXY& T, int rs, int ps) {
+        const int slot = r * 256 + tid;
+        const int p = SPLIT ? (slot >> 2) : (slot >> 3);
+        const int sub = SPLIT ? (slot & 3) * 8 : (slot & 7) * 4;
+        const int hy = p / HALO_W, hx = p - hy * HALO_W;
+        const int gy = T.y0 - 1 + hy, gx = T.x0 - 1 + hx;
+        const bool ok = (slot < (SPLIT ? SP_SLOTS : IN_SLOTS)) && (gy >= 0) && (gy < P.H) && (gx >= 0) && (gx < P.W);
+        return ok ? gy * rs + gx * ps + sub : -1;
+    };
+    int goff[SPLIT ? NR : 1]; // split mode keeps the 6 offsets in registers; fp32 mode (11 slots) recomputes them
+    auto tile_offsets = [&](const TileXY& T, int rs, int ps) {
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int r = 0; r < IN_ROUNDS; ++r) {
-            const int slot = r * 256 + tid;
-            const int p = slot >> 3, c = slot & 7;
-            const int hy = p / HALO_W, hx = p - hy * HALO_W;
-            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-            const bool ok = (slot < IN_SLOTS) && (gy >= 0) && (gy < P.H) && (gx >= 0) && (gx < P.W);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(base + (long long)gy * pl.rs + gx * pl.ps + c * 4);
-            pin[r] = v;
+            for (int r = 0; r < NR; ++r) goff[r] = slot_offset(r, T, rs, ps);
+        }
+    };
+    auto load_in = [&](int s, const TileXY& T) {
+        const PlaneIn pl = P.in[s];
+        const float* base = pl.p + (long long)T.b * pl.bs;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if constexpr (!SPLIT) {
+                const int off = slot_offset(r, T, pl.rs, pl.ps);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (off >= 0) v = *reinterpret_cast<const f32x4*>(base + off);
+                pin[r] = v;
+            } else {
+                f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+                if (goff[r] >= 0) {
+                    const f32x4* src = reinterpret_cast<const f32x4*>(base + goff[r]);
+                    v0 = src[0];
+                    v1 = src[1];
+                }
+                pin[2 * r] = v0;
+                pin[2 * r + 1] = v1;
+            }
         }
     };
     auto store_in = [&]() {
+        if constexpr (!SPLIT) {
 #pragma unroll
-        for (int r = 0; r < IN_ROUNDS; ++r) {
-            const int slot = r * 256 + tid;
-            const int p = slot >> 3, c = slot & 7;
-            if (slot < IN_SLOTS) *reinterpret_cast<f32x4*>(in_lds + swz_off(p, c)) = pin[r];
+            for (int r = 0; r < IN_ROUNDS; ++r) {
+                const int slot = r * 256 + tid;
+                const int p = slot >> 3, c = slot & 7;
+                const int hy = p / HALO_W, hx = p - hy * HALO_W;
+                if (slot < IN_SLOTS) *reinterpret_cast<f32x4*>(in_lds + swz_off(hy, hx, c)) = pin[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < SP_ROUNDS; ++r) {
+                const int slot = r * 256 + tid;
+                const int p = slot >> 2, o = slot & 3;
+                const int hy = p / HALO_W, hx = p - hy * HALO_W;
+                if (slot < SP_SLOTS) {
+                    u16x8 hi, lo;
+                    split8(pin[2 * r], pin[2 * r + 1], hi, lo);
+                    *reinterpret_cast<u16x8*>(in_lds + swz_off(hy, hx, o)) = hi;       // channels 8o..8o+7, hi terms
+                    *reinterpret_cast<u16x8*>(in_lds + swz_off(hy, hx, 4 + o)) = lo;   // same channels, lo terms
+                }
+            }
         }
     };
     auto load_w = [&](int s) {
@@ -96,114 +180,198 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
     };
 
     f32x16 acc[2];
+    // D = W (rows = output channel) x X (cols = pixel): lane = (pixel l31, half h); register i holds channel
+    // co(i) = (i&3) + 8*(i>>2) + 4h, i.e. four float4 groups q = 0..3 at channels 8q + 4h .. +3.
     auto init_acc = [&](int j) {
-        const float bv = P.bias ? P.bias[j * 32 + l31] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc[0][i] = bv; acc[1][i] = bv; }
+        for (int q = 0; q < 4; ++q) {
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (P.bias) bv = *reinterpret_cast<const f32x4*>(P.bias + j * 32 + 8 * q + 4 * h);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { acc[0][4 * q + t] = bv[t]; acc[1][4 * q + t] = bv[t]; }
+        }
     };
 
+    const char* wl = w_lds + lane * 16;
     auto compute = [&]() {
-#pragma unroll 1
+#pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - dy * 3;
-            f32x4 bf[4];
+            if constexpr (!SPLIT) {
+                f32x4 bf[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(w_lds + ((tap * 4 + j) * 64 + lane) * 16);
+                for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f32x4*>(wl + (tap * 4 + j) * 1024);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int p = (wv * 2 + r + dy) * HALO_W + l31 + dx;
-                f32x4 af[4];
+                for (int r = 0; r < 2; ++r) {
+                    f32x4 af[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const f32x4*>(in_lds + swz_off(p, 4 * h + j));
+                    for (int j = 0; j < 4; ++j)
+                        af[j] = *reinterpret_cast<const f32x4*>(in_lds + abase[dx][j] + (r + dy) * ROW_BYTES);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][q], bf[j][q], acc[r], 0, 0, 0);
+                        for (int q = 0; q < 4; ++q)
+                            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][q], af[j][q], acc[r], 0, 0, 0);
+                }
+            } else {
+                // weight fragments [tap][kstep s2][hi|lo][lane]: 8 bf16 = input channels 16*s2 + 8h + 0..7, column co = l31
+                bf16x8 bh[2], bl[2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bh[s2] = *reinterpret_cast<const bf16x8*>(wl + ((tap * 2 + s2) * 2 + 0) * 1024);
+                    bl[s2] = *reinterpret_cast<const bf16x8*>(wl + ((tap * 2 + s2) * 2 + 1) * 1024);
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    bf16x8 ah[2], al[2];
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        ah[s2] = *reinterpret_cast<const bf16x8*>(in_lds + abase[dx][s2] + (r + dy) * ROW_BYTES);
+                        al[s2] = *reinterpret_cast<const bf16x8*>(in_lds + abase[dx][2 + s2] + (r + dy) * ROW_BYTES);
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s2], al[s2], acc[r], 0, 0, 0);
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[s2], ah[s2], acc[r], 0, 0, 0);
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s2], ah[s2], acc[r], 0, 0, 0);
+                    }
+                }
             }
         }
     };
 
-    auto epilogue = [&](int j) {
+    // Epilogue: each lane owns one pixel and 16 channels as four float4 groups -> 16-B loads/stores; lanes l and l+32
+    // cover adjacent 16-B chunks, so every store instruction writes 32 x 32 contiguous bytes.
+    auto epilogue = [&](int j, const TileXY& T) {
         const OutDesc o = P.out[j];
-        float* dst = o.p + (long long)b * o.bs;
-        const long long sb = (long long)b * P.std_bs;
+        float* dst = o.p + (long long)T.b * o.bs;
+        const long long sb = (long long)T.b * P.std_bs;
+        const int x = T.x0 + l31;
+        if (x >= P.W) return;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int y = y0 + wv * 2 + r;
+            const int y = T.y0 + wv * 2 + r;
             if (y >= P.H) continue;
+            float* dp = dst + (long long)y * o.rs + (long long)x * o.ps + 4 * h;
+            const long long os = sb + (long long)y * P.std_rs + x * 32 + 4 * h;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int x = x0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (x >= P.W) continue;
-                const long long od = (long long)y * o.rs + (long long)x * o.ps + l31;
-                const long long os = sb + (long long)y * P.std_rs + x * 32 + l31;
-                float v = acc[r][i] * o.a1;
-                if (o.accumulate) v += dst[od];
-                if (o.e1) v += o.s1 * o.e1[os];
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = acc[r][4 * q + t] * o.a1;
+                if (o.accumulate) v += *reinterpret_cast<const f32x4*>(dp + 8 * q);
+                if (o.e1) v += o.s1 * *reinterpret_cast<const f32x4*>(o.e1 + os + 8 * q);
                 v *= o.a2;
-                if (o.e2) v += o.s2 * o.e2[os];
-                if (o.e3) v += o.s3 * o.e3[os];
-                v = v > 0.f ? v : v * o.slope;
-                if (o.mask) v = o.mask[os] > 0.f ? v : v * o.mslope;
-                dst[od] = v;
+                if (o.e2) v += o.s2 * *reinterpret_cast<const f32x4*>(o.e2 + os + 8 * q);
+                if (o.e3) v += o.s3 * *reinterpret_cast<const f32x4*>(o.e3 + os + 8 * q);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = v[t] > 0.f ? v[t] : v[t] * o.slope;
+                if (o.mask) {
+                    const f32x4 m = *reinterpret_cast<const f32x4*>(o.mask + os + 8 * q);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = m[t] > 0.f ? v[t] : v[t] * o.mslope;
+                }
+                *reinterpret_cast<f32x4*>(dp + 8 * q) = v;
             }
         }
     };
 
-    // ---- prologue: stage step 0
-    load_in(0);
+    if (items <= 0) return;
+    // diagnostic stamps (P.dbg != null only in profiling builds of the HOST side; never in timed runs)
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t0 = 0;
+    const bool stamp = P.dbg != nullptr;
+    auto tick = [&](int i) {
+        if (stamp) { const unsigned long long t = __builtin_readcyclecounter(); st[i] += t - t0; t0 = t; }
+    };
+    if (stamp) t0 = __builtin_readcyclecounter();
+    // ---- prologue: stage item 0
+    TileXY cur = tile_of(0);
+    tile_offsets(cur, P.in[0].rs, P.in[0].ps);
+    load_in(0, cur);
     load_w(0);
     store_in();
     store_w();
     __syncthreads();
+    tick(0);
 
-    if (!MULTI_OUT) init_acc(0);
+    int s = 0, k = 0; // step within tile, tile ordinal
 #pragma unroll 1
-    for (int s = 0; s < nsteps; ++s) {
-        const bool more = (s + 1 < nsteps);
+    for (int it = 0; it < items; ++it) {
+        const bool more = (it + 1 < items);
+        const int s_next = (s + 1 == nsteps) ? 0 : s + 1;
+        TileXY nxt = cur;
         if (more) {
-            if (!MULTI_OUT) load_in(s + 1);
-            load_w(s + 1);
+            if (s_next == 0) { nxt = tile_of(k + 1); tile_offsets(nxt, P.in[0].rs, P.in[0].ps); }
+            if (!MULTI_OUT || s_next == 0) load_in(MULTI_OUT ? 0 : s_next, nxt);
+            load_w(s_next);
         }
-        if (MULTI_OUT) init_acc(s);
+        tick(1);
+        if (MULTI_OUT || s == 0) init_acc(MULTI_OUT ? s : 0);
         compute();
-        if (MULTI_OUT) epilogue(s);
+        tick(2);
+        if (MULTI_OUT) epilogue(s, cur);
+        else if (s == nsteps - 1) epilogue(0, cur);
+        tick(3);
         if (more) {
             __syncthreads();
-            if (!MULTI_OUT) store_in();
+            tick(4);
+            if (!MULTI_OUT || s_next == 0) store_in();
             store_w();
             __syncthreads();
+            tick(5);
         }
+        if (s_next == 0) { cur = nxt; ++k; }
+        s = s_next;
     }
-    if (!MULTI_OUT) epilogue(0);
+    if (stamp && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) atomicAdd(&P.dbg[i], st[i]);
+        atomicAdd(&P.dbg[6], (unsigned long long)items);
+    }
 }
 
+template <bool M, bool S>
+static hipError_t set_lds()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<M, S>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES);
+}
 static hipError_t set_lds_once()
 {
     static bool done = false;
     if (done) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES);
-    if (e != hipSuccess) return e;
+    hipError_t e;
+    if ((e = set_lds<false, false>()) != hipSuccess) return e;
+    if ((e = set_lds<true, false>()) != hipSuccess) return e;
+    if ((e = set_lds<false, true>()) != hipSuccess) return e;
+    if ((e = set_lds<true, true>()) != hipSuccess) return e;
     done = true;
     return hipSuccess;
 }
 
-hipError_t launch_conv3x3_mfma(const ConvParams& p, hipStream_t stream)
+// split != 0 selects the bf16x3 math mode; p.wpanel must then point at panels written by pack_weights_split_kernel
+hipError_t launch_conv3x3_mfma(const ConvParams& p, int split, hipStream_t stream)
 {
     hipError_t e = set_lds_once();
     if (e != hipSuccess) return e;
     const int ntiles = p.B * p.tilesX * p.tilesY;
     if (ntiles <= 0) return hipSuccess;
-    if (p.n_out > 1)
-        hipLaunchKernelGGL(conv3x3_mfma_kernel<true>, dim3(ntiles), dim3(256), CONV_LDS_BYTES, stream, p);
-    else
-        hipLaunchKernelGGL(conv3x3_mfma_kernel<false>, dim3(ntiles), dim3(256), CONV_LDS_BYTES, stream, p);
+    int ncu = 256;
+    {
+        static int cached = 0;
+        if (!cached) { hipDeviceProp_t prop; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached = prop.multiProcessorCount; else cached = 256; }
+        ncu = cached;
+    }
+    const int resident = 2 * ncu; // 2 workgroups per CU (LDS 80,384 B each)
+    const dim3 g(ntiles < resident ? ntiles : resident), b(256);
+    if (p.n_out > 1) {
+        if (split) hipLaunchKernelGGL((conv3x3_mfma_kernel<true, true>), g, b, CONV_LDS_BYTES, stream, p);
+        else hipLaunchKernelGGL((conv3x3_mfma_kernel<true, false>), g, b, CONV_LDS_BYTES, stream, p);
+    } else {
+        if (split) hipLaunchKernelGGL((conv3x3_mfma_kernel<false, true>), g, b, CONV_LDS_BYTES, stream, p);
+        else hipLaunchKernelGGL((conv3x3_mfma_kernel<false, false>), g, b, CONV_LDS_BYTES, stream, p);
+    }
     return hipGetLastError();
 }
 

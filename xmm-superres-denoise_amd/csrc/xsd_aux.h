@@ -15,7 +15,7 @@ struct MaskPadParams {
     float max_val;
 };
 
-hipError_t launch_conv3x3_mfma(const ConvParams& p, hipStream_t stream);
+hipError_t launch_conv3x3_mfma(const ConvParams& p, int split, hipStream_t stream);
 hipError_t launch_wgrad_mfma(const WgradParams& p, hipStream_t stream);
 hipError_t launch_wgrad_reduce(const WgradReduceParams& r, hipStream_t stream);
 hipError_t launch_edge_expand(const EdgeExpandParams& p, hipStream_t s);
@@ -28,6 +28,8 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, long long n
                        float eps, float gscale, hipStream_t s);
 hipError_t launch_pack_weights(const float* params, const PackDesc* descs_dev, int ndesc, float* fwd, float* bwd,
                                hipStream_t s);
+hipError_t launch_pack_weights_split(const float* params, const PackDesc* descs_dev, int ndesc, unsigned short* fwd,
+                                     unsigned short* bwd, hipStream_t s);
 hipError_t launch_pack_edge(const float* w_first, const float* w_last, float* ff, float* fb, float* lf, float* lb,
                             hipStream_t s);
 hipError_t launch_mask_pad_normalize(const MaskPadParams& p, hipStream_t s);

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -67,6 +68,9 @@ struct xsd_engine {
     // packed weights
     float* pk_fwd = nullptr;
     float* pk_bwd = nullptr;
+    unsigned short* pk_fwd_s = nullptr; // bf16x3 (hi|lo) panels, same byte size / offsets as pk_fwd / pk_bwd
+    unsigned short* pk_bwd_s = nullptr;
+    int math = 0;              // 0 = exact fp32 MFMA, 1 = bf16x3 split MFMA (conv forward + input-gradient)
     float* pk_edge = nullptr; // first_fwd, first_bwd, last_fwd, last_bwd (288 each)
     float* pk_sbias = nullptr;
     PackDesc* descs_dev = nullptr;
@@ -93,6 +97,7 @@ struct xsd_engine {
     const float* b_dy = nullptr;
     float* b_dx = nullptr;
     float* b_grads = nullptr;
+    unsigned long long* dbg = nullptr; // conv phase stamps (diagnostic)
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -162,6 +167,14 @@ struct Builder {
         freelist[level].push_back(reinterpret_cast<uintptr_t>(p) - base);
     }
 
+    const float* fwdp(long long off) const
+    {
+        return e->math ? reinterpret_cast<const float*>(e->pk_fwd_s) + off : e->pk_fwd + off;
+    }
+    const float* bwdp(long long off) const
+    {
+        return e->math ? reinterpret_cast<const float*>(e->pk_bwd_s) + off : e->pk_bwd + off;
+    }
     ConvParams conv_base(int level) const
     {
         ConvParams p;
@@ -204,7 +217,8 @@ struct Builder {
         const double bytes = 128.0 * (p.n_in + p.n_out) * px;
         return [eng, p, bias_from_params, bias_off, flop, bytes](hipStream_t s) mutable {
             if (bias_from_params) p.bias = eng->params + bias_off;
-            return prof_launch(eng, 0, flop, bytes, s, [&]() { return launch_conv3x3_mfma(p, s); });
+            p.dbg = eng->dbg;
+            return prof_launch(eng, 0, flop, bytes, s, [&]() { return launch_conv3x3_mfma(p, eng->math, s); });
         };
     }
     // wgrad + fixed-order reduce into the flat gradient vector
@@ -272,7 +286,7 @@ struct Builder {
                     p.n_in = c + 1; p.n_out = 1;
                     p.in[0] = std_in(a.xin, 0);
                     for (int k = 0; k < c; ++k) p.in[k + 1] = std_in(a.xs[k], 0);
-                    p.wpanel = e->pk_fwd + cw.fwd_off;
+                    p.wpanel = fwdp(cw.fwd_off);
                     float* o = alloc(0);
                     std_out(p.out[0], o, 0);
                     if (c < 4) { p.out[0].slope = 0.2f; a.xs[c] = o; }     // rrdb_blocks.py:38-52
@@ -293,7 +307,7 @@ struct Builder {
         float* T = alloc(0);
         { // fea + trunk_conv(rrdb(fea)) (generator_rrdb.py:68-69)
             ConvParams p = conv_base(0);
-            p.n_in = 1; p.n_out = 1; p.in[0] = std_in(cur, 0); p.wpanel = e->pk_fwd + e->trunk.fwd_off;
+            p.n_in = 1; p.n_out = 1; p.in[0] = std_in(cur, 0); p.wpanel = fwdp(e->trunk.fwd_off);
             std_out(p.out[0], T, 0);
             p.out[0].e1 = fea; p.out[0].s1 = 1.f;
             F.push_back(conv_launch(p, true, e->trunk.b_off));
@@ -310,7 +324,7 @@ struct Builder {
             for (int u = 0; u < nup; ++u) { // upsampling: conv 32->128, LeakyReLU(0.01), PixelShuffle(2) (generator_rrdb.py:93-99)
                 U[u] = alloc(u + 1);
                 ConvParams p = conv_base(u);
-                p.n_in = 1; p.n_out = 4; p.in[0] = std_in(feat, u); p.wpanel = e->pk_fwd + e->up[u].fwd_off;
+                p.n_in = 1; p.n_out = 4; p.in[0] = std_in(feat, u); p.wpanel = fwdp(e->up[u].fwd_off);
                 for (int n = 0; n < 4; ++n) { shuf_out(p.out[n], U[u], u, n); p.out[n].slope = 0.01f; }
                 p.bias = e->pk_sbias + e->up[u].sbias_off;
                 F.push_back(conv_launch(p, false, 0));
@@ -320,7 +334,7 @@ struct Builder {
             H1 = alloc(lo);
             { // lrelu(HRconv(fea)) (generator_rrdb.py:107)
                 ConvParams p = conv_base(lo);
-                p.n_in = 1; p.n_out = 1; p.in[0] = std_in(feat, lo); p.wpanel = e->pk_fwd + e->hr.fwd_off;
+                p.n_in = 1; p.n_out = 1; p.in[0] = std_in(feat, lo); p.wpanel = fwdp(e->hr.fwd_off);
                 std_out(p.out[0], H1, lo); p.out[0].slope = 0.2f;
                 F.push_back(conv_launch(p, true, e->hr.b_off));
             }
@@ -368,7 +382,7 @@ struct Builder {
                 float* G = nup > 0 ? alloc(lo) : dT;
                 { // HRconv input gradient (masked by the upsample LeakyReLU(0.01) when it feeds a pixel-shuffle)
                     ConvParams p = conv_base(lo);
-                    p.n_in = 1; p.n_out = 1; p.in[0] = std_in(GH, lo); p.wpanel = e->pk_bwd + e->hr.bwd_off;
+                    p.n_in = 1; p.n_out = 1; p.in[0] = std_in(GH, lo); p.wpanel = bwdp(e->hr.bwd_off);
                     std_out(p.out[0], G, lo);
                     if (nup > 0) { p.out[0].mask = U[nup - 1]; p.out[0].mslope = 0.01f; }
                     S.push_back(conv_launch(p, false, 0));
@@ -382,7 +396,7 @@ struct Builder {
                     ConvParams p = conv_base(u);
                     p.n_in = 4; p.n_out = 1;
                     for (int n = 0; n < 4; ++n) p.in[n] = gs[n];
-                    p.wpanel = e->pk_bwd + e->up[u].bwd_off;
+                    p.wpanel = bwdp(e->up[u].bwd_off);
                     std_out(p.out[0], Gn, u);
                     if (u > 0) { p.out[0].mask = U[u - 1]; p.out[0].mslope = 0.01f; }
                     S.push_back(conv_launch(p, false, 0));
@@ -395,7 +409,7 @@ struct Builder {
         float* dR = alloc(0);
         {
             ConvParams p = conv_base(0);
-            p.n_in = 1; p.n_out = 1; p.in[0] = std_in(dT, 0); p.wpanel = e->pk_bwd + e->trunk.bwd_off;
+            p.n_in = 1; p.n_out = 1; p.in[0] = std_in(dT, 0); p.wpanel = bwdp(e->trunk.bwd_off);
             std_out(p.out[0], dR, 0);
             e->bwd_stages[0].push_back(conv_launch(p, false, 0));
         }
@@ -415,7 +429,7 @@ struct Builder {
                     for (int k = 0; k <= c; ++k) xs.push_back(std_in(xpl[k], 0));
                     wgrad_launch(S, 0, xs, {std_in(G, 0)}, cw[c], c == 4 ? gscale : 1.f);
                     ConvParams p = conv_base(0);
-                    p.n_in = 1; p.n_out = c + 1; p.in[0] = std_in(G, 0); p.wpanel = e->pk_bwd + cw[c].bwd_off;
+                    p.n_in = 1; p.n_out = c + 1; p.in[0] = std_in(G, 0); p.wpanel = bwdp(cw[c].bwd_off);
                     for (int j = 0; j <= c; ++j) {
                         OutDesc& o = p.out[j];
                         std_out(o, dS[j], 0);
@@ -495,6 +509,7 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(XSD_ERR_HIP, "no HIP device available");
     xsd_engine* e = new xsd_engine();
     e->cfg = *cfg;
+    if (const char* m = getenv("XSD_MATH")) e->math = (strcmp(m, "bf16x3") == 0 || strcmp(m, "1") == 0) ? 1 : 0;
     const int blocks = cfg->num_res_blocks, nup = cfg->kind == XSD_KIND_SR ? cfg->num_upsample : 0;
     long long off = 0, pk = 0, sb = 0;
     take_conv(off, 32, 1, e->first_w, e->first_b);
@@ -529,6 +544,8 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
 #define CK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { int rc = fail(XSD_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); xsd_destroy(e); return rc; } } while (0)
     CK(hipMalloc((void**)&e->pk_fwd, sizeof(float) * pk));
     CK(hipMalloc((void**)&e->pk_bwd, sizeof(float) * pk));
+    CK(hipMalloc((void**)&e->pk_fwd_s, sizeof(float) * pk));
+    CK(hipMalloc((void**)&e->pk_bwd_s, sizeof(float) * pk));
     CK(hipMalloc((void**)&e->pk_edge, sizeof(float) * 4 * 288));
     CK(hipMalloc((void**)&e->pk_sbias, sizeof(float) * (sb ? sb : 1)));
     CK(hipMalloc((void**)&e->descs_dev, sizeof(PackDesc) * descs.size()));
@@ -547,7 +564,7 @@ void xsd_destroy(xsd_engine* e)
     if (!e) return;
     hipDeviceSynchronize();
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
-    hipFree(e->pk_fwd); hipFree(e->pk_bwd); hipFree(e->pk_edge); hipFree(e->pk_sbias); hipFree(e->descs_dev);
+    hipFree(e->pk_fwd); hipFree(e->pk_bwd); hipFree(e->pk_fwd_s); hipFree(e->pk_bwd_s); hipFree(e->pk_edge); hipFree(e->pk_sbias); hipFree(e->descs_dev);
     hipFree(e->wg_partial); hipFree(e->wg_bias_partial); hipFree(e->edge_partial); hipFree(e->loss_partial);
     hipFree(e->ws);
     delete e;
@@ -555,12 +572,23 @@ void xsd_destroy(xsd_engine* e)
 
 int64_t xsd_param_count(const xsd_engine* e) { return e ? e->nparams : 0; }
 
+int xsd_set_math(xsd_engine* e, int mode)
+{
+    if (!e || (mode != 0 && mode != 1)) return fail(XSD_ERR_ARG, "math mode must be 0 (fp32) or 1 (bf16x3)");
+    if (mode != e->math) { e->math = mode; e->packed = false; e->pB = 0; e->ptrain = -1; e->fwd_saved = false; }
+    return XSD_OK;
+}
+int xsd_get_math(const xsd_engine* e) { return e ? e->math : -1; }
+
 int xsd_pack_weights(xsd_engine* e, const float* dev_params, void* stream)
 {
     if (!e || !dev_params) return fail(XSD_ERR_ARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
     e->params = dev_params;
-    HIPCHK(launch_pack_weights(dev_params, e->descs_dev, e->ndesc, e->pk_fwd, e->pk_bwd, s));
+    if (e->math)
+        HIPCHK(launch_pack_weights_split(dev_params, e->descs_dev, e->ndesc, e->pk_fwd_s, e->pk_bwd_s, s));
+    else
+        HIPCHK(launch_pack_weights(dev_params, e->descs_dev, e->ndesc, e->pk_fwd, e->pk_bwd, s));
     HIPCHK(launch_pack_edge(dev_params + e->first_w, dev_params + e->last_w, e->pk_edge, e->pk_edge + 288, e->pk_edge + 576,
                             e->pk_edge + 864, s));
     for (auto& c : e->up) HIPCHK(launch_pack_shuffle_bias(dev_params + c.b_off, e->pk_sbias + c.sbias_off, s));
@@ -666,6 +694,19 @@ int xsd_image_upsample(const float* dev_in, float* dev_out, int N, int H, int W,
     return XSD_OK;
 }
 
+// diagnostic: accumulate shader-cycle stamps of the conv kernel's phases (enable != 0 allocates/zeroes; read copies out)
+int xsd_debug_stamps(xsd_engine* e, int enable, unsigned long long* out8)
+{
+    if (!e) return fail(XSD_ERR_ARG, "null engine");
+    HIPCHK(hipDeviceSynchronize());
+    if (out8 && e->dbg) HIPCHK(hipMemcpy(out8, e->dbg, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (enable) {
+        if (!e->dbg) HIPCHK(hipMalloc((void**)&e->dbg, 8 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(e->dbg, 0, 8 * sizeof(unsigned long long)));
+    } else if (e->dbg) { hipFree(e->dbg); e->dbg = nullptr; }
+    return XSD_OK;
+}
+
 int xsd_profile_enable(xsd_engine* e, int enable)
 {
     if (!e) return fail(XSD_ERR_ARG, "null engine");
@@ -693,7 +734,7 @@ int xsd_profile_read(xsd_engine* e, int klass, double* total_ms, int64_t* launch
 }
 
 // ---- single-layer test hooks ---------------------------------------------------------------------------------
-static int pack_single(const float* dev_w, int cout, int cin, float** fwd, float** bwd, hipStream_t s)
+static int pack_single(const float* dev_w, int cout, int cin, float** fwd, float** bwd, int math, hipStream_t s)
 {
     const long long n = (long long)(cout / 32) * (cin / 32) * PANEL_FLOATS;
     PackDesc d; d.src_w = 0; d.dst_fwd = 0; d.dst_bwd = 0; d.cout = cout; d.cin = cin; d.shuffle = 0; d.pad = 0;
@@ -702,7 +743,8 @@ static int pack_single(const float* dev_w, int cout, int cin, float** fwd, float
     HIPCHK(hipMalloc((void**)bwd, sizeof(float) * n));
     HIPCHK(hipMalloc((void**)&dd, sizeof(PackDesc)));
     HIPCHK(hipMemcpy(dd, &d, sizeof(d), hipMemcpyHostToDevice));
-    HIPCHK(launch_pack_weights(dev_w, dd, 1, *fwd, *bwd, s));
+    if (math) HIPCHK(launch_pack_weights_split(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
+    else HIPCHK(launch_pack_weights(dev_w, dd, 1, *fwd, *bwd, s));
     HIPCHK(hipStreamSynchronize(s));
     hipFree(dd);
     return XSD_OK;
@@ -714,14 +756,14 @@ int xsd_test_conv3x3(xsd_engine* e, const float* const* in_planes, int n_in, con
     if (!e || n_in < 1 || n_in > 5 || n_out < 1 || n_out > 5 || (n_in > 1 && n_out > 1)) return fail(XSD_ERR_ARG, "bad n_in/n_out");
     hipStream_t s = (hipStream_t)stream;
     float *fwd = nullptr, *bwd = nullptr;
-    int rc = pack_single(dev_w_oihw, 32 * n_out, 32 * n_in, &fwd, &bwd, s);
+    int rc = pack_single(dev_w_oihw, 32 * n_out, 32 * n_in, &fwd, &bwd, e->math, s);
     if (rc) return rc;
     Builder b(e, B, H, W, false, 0);
     ConvParams p = b.conv_base(0);
     p.n_in = n_in; p.n_out = n_out; p.wpanel = fwd; p.bias = dev_bias;
     for (int i = 0; i < n_in; ++i) p.in[i] = b.std_in(in_planes[i], 0);
     for (int j = 0; j < n_out; ++j) { b.std_out(p.out[j], out_planes[j], 0); p.out[j].slope = slope; }
-    hipError_t err = launch_conv3x3_mfma(p, s);
+    hipError_t err = launch_conv3x3_mfma(p, e->math, s);
     hipStreamSynchronize(s);
     hipFree(fwd); hipFree(bwd);
     if (err != hipSuccess) return fail(XSD_ERR_HIP, "conv launch: %s", hipGetErrorString(err));
@@ -734,13 +776,13 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
     if (!e || n_in < 1 || n_in > 5) return fail(XSD_ERR_ARG, "bad n_in");
     hipStream_t s = (hipStream_t)stream;
     float *fwd = nullptr, *bwd = nullptr;
-    int rc = pack_single(dev_w_oihw, 32, 32 * n_in, &fwd, &bwd, s);
+    int rc = pack_single(dev_w_oihw, 32, 32 * n_in, &fwd, &bwd, e->math, s);
     if (rc) return rc;
     Builder b(e, B, H, W, false, 0);
     ConvParams p = b.conv_base(0);
     p.n_in = 1; p.n_out = n_in; p.wpanel = bwd; p.in[0] = b.std_in(dev_g_plane, 0);
     for (int j = 0; j < n_in; ++j) b.std_out(p.out[j], dx_planes[j], 0);
-    hipError_t err = launch_conv3x3_mfma(p, s);
+    hipError_t err = launch_conv3x3_mfma(p, e->math, s);
     if (err == hipSuccess) {
         WgradParams wp; memset(&wp, 0, sizeof(wp));
         wp.B = B; wp.H = H; wp.W = W; wp.tilesX = p.tilesX; wp.tilesY = p.tilesY; wp.n_in = n_in; wp.n_g = 1; wp.nparts = e->nparts;

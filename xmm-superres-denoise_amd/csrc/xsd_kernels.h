@@ -52,6 +52,7 @@ struct ConvParams {
     PlaneIn in[5];
     const float* wpanel; // [n_out][n_in] panels (one of the two is 1), PANEL_FLOATS each
     const float* bias;   // [n_out*32] or nullptr
+    unsigned long long* dbg; // diagnostic phase stamps (null in production): [grid][8] accumulated shader cycles
     OutDesc out[5];
 };
 

@@ -48,6 +48,8 @@ def load():
     L.xsd_param_count.argtypes = [vp]
     L.xsd_param_count.restype = i64
     L.xsd_pack_weights.argtypes = [vp, fp, vp]
+    L.xsd_set_math.argtypes = [vp, i32]
+    L.xsd_get_math.argtypes = [vp]
     L.xsd_forward.argtypes = [vp, fp, fp, i32, i32, i32, i32, vp]
     L.xsd_backward.argtypes = [vp, fp, fp, fp, vp]
     L.xsd_backward_num_stages.argtypes = [vp]
@@ -59,6 +61,7 @@ def load():
     L.xsd_normalize.argtypes = [fp, fp, i64, f32, i32, i32, vp]
     L.xsd_image_upsample.argtypes = [fp, fp, i32, i32, i32, i32, vp]
     L.xsd_profile_enable.argtypes = [vp, i32]
+    L.xsd_debug_stamps.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64)]
     L.xsd_profile_read.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64),
                                    ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     L.xsd_test_conv3x3.argtypes = [vp, ctypes.POINTER(vp), i32, fp, fp, ctypes.POINTER(vp), i32, f32, i32, i32, i32, vp]
@@ -69,10 +72,10 @@ def load():
 
 # every symbol include/xsd.h declares (checked by tests/test_abi.py without a GPU)
 ABI_SYMBOLS = [
-    "xsd_last_error", "xsd_version", "xsd_create", "xsd_destroy", "xsd_param_count", "xsd_pack_weights",
+    "xsd_last_error", "xsd_version", "xsd_create", "xsd_destroy", "xsd_param_count", "xsd_set_math", "xsd_get_math", "xsd_pack_weights",
     "xsd_forward", "xsd_backward", "xsd_backward_num_stages", "xsd_backward_stage", "xsd_grad_range",
     "xsd_l1_loss", "xsd_adam_step", "xsd_mask_pad_normalize", "xsd_normalize", "xsd_image_upsample",
-    "xsd_profile_enable", "xsd_profile_read", "xsd_test_conv3x3", "xsd_test_conv3x3_bwd",
+    "xsd_profile_enable", "xsd_profile_read", "xsd_debug_stamps", "xsd_test_conv3x3", "xsd_test_conv3x3_bwd",
 ]
 
 

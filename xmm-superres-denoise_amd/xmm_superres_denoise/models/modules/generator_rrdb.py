@@ -69,6 +69,7 @@ class _GeneratorRRDB(nn.Module):
         self._engine_dev = None
         self._flat = None
         self._plist = None
+        self._math = None  # None: engine default (env XSD_MATH, else fp32)
 
     # ---- flat parameter buffer ---------------------------------------------------------------------------------
     def _num_upsample(self):
@@ -103,6 +104,15 @@ class _GeneratorRRDB(nn.Module):
     def flat_parameters(self) -> torch.Tensor:
         return self.flatten_parameters()
 
+    def set_math(self, mode: str):
+        """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA with fp32 accumulation, ~5e-6 whole-net error)."""
+        if mode not in ("fp32", "bf16x3"):
+            raise ValueError(mode)
+        self._math = mode
+        if self._engine is not None:
+            self._engine.set_math(mode)
+        return self
+
     def _get_engine(self, device):
         if not torch.device(device).type == "cuda":
             raise XsdError("the MI355X engine needs CUDA(HIP) tensors; there is no CPU fallback")
@@ -114,6 +124,8 @@ class _GeneratorRRDB(nn.Module):
                 self._engine = Engine(self._kind, self.in_channels, self.out_channels, self.num_filters,
                                       self.num_res_blocks, self._num_upsample(), self.memory_efficient)
             self._engine_dev = flat.device
+            if self._math is not None:
+                self._engine.set_math(self._math)
         return self._engine
 
     def forward(self, x):
