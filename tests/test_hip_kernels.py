@@ -67,8 +67,8 @@ def test_conv3x3_backward(eng, n_in, shape):
     check(eng.L.xsd_test_conv3x3_bwd(eng.h, ptr_array(xin), n_in, wd.data_ptr(), gp.data_ptr(), ptr_array(dxs),
                                      dw.data_ptr(), db.data_ptr(), B, H, W, None))
     assert _rel(planes_to_nchw(dxs), dx_ref) < eng.tol
-    assert _rel(dw.cpu().numpy(), dw_ref) < 5e-5
-    assert _rel(db.cpu().numpy(), db_ref) < 5e-5
+    assert _rel(dw.cpu().numpy(), dw_ref) < max(5e-5, eng.tol)
+    assert _rel(db.cpu().numpy(), db_ref) < max(5e-5, eng.tol)
 
 
 def test_wgrad_is_bitwise_reproducible(eng):

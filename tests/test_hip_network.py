@@ -37,7 +37,7 @@ def test_golden_forward_backward(name, kind, math):
     loss = torch.nn.functional.l1_loss(y, torch.from_numpy(t).cuda())
     assert abs(loss.item() - float(z["loss"][0])) < 1e-5
     loss.backward()
-    assert_grad_close(xd.grad.cpu().numpy()[:, 0], z["dx"][:, 0], "dx", tight=2 * TIGHT[math], loose=5e-2)
+    assert_grad_close(xd.grad.cpu().numpy().reshape(-1, x.shape[-1]), z["dx"].reshape(-1, x.shape[-1]), "dx", tight=2 * TIGHT[math], loose=5e-2, max_flip_frac=0.3)
     names = [str(n) for n in z["param_names"]]
     params = dict(m.named_parameters())
     assert list(params.keys()) == names
@@ -76,7 +76,7 @@ def test_fresh_inputs_vs_oracle(kind, shape, math):
     dx = eng.backward(dy, grads, need_dx=True)
     assert np.abs(y.cpu().numpy() - yo).max() < 1e-4
     assert abs(loss.item() - lo) < 1e-5
-    assert_grad_close(dx.cpu().numpy()[:, 0], dxo[:, 0], "dx", tight=2 * TIGHT[math], loose=5e-2)
+    assert_grad_close(dx.cpu().numpy().reshape(-1, dxo.shape[-1]), dxo.reshape(-1, dxo.shape[-1]), "dx", tight=2 * TIGHT[math], loose=5e-2, max_flip_frac=0.3)
     g = grads.cpu().numpy()
     shapes = gc.rrdb_param_shapes(kind, 32, 2, num_upsample=1)
     off = 0

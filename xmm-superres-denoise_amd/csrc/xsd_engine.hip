@@ -245,7 +245,7 @@ struct Builder {
             wp.partial = eng->wg_partial; wp.bias_partial = eng->wg_bias_partial;
             rp.partial = eng->wg_partial; rp.bias_partial = eng->wg_bias_partial;
             rp.dw = eng->b_grads + w_off; rp.db = eng->b_grads + b_off;
-            hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return launch_wgrad_mfma(wp, s); });
+            hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return launch_wgrad_mfma(wp, eng->math, s); });
             if (err != hipSuccess) return err;
             return launch_wgrad_reduce(rp, s);
         });
@@ -789,7 +789,7 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
         for (int i = 0; i < n_in; ++i) wp.x[i] = b.std_in(in_planes[i], 0);
         wp.g[0] = b.std_in(dev_g_plane, 0);
         wp.partial = e->wg_partial; wp.bias_partial = e->wg_bias_partial;
-        err = launch_wgrad_mfma(wp, s);
+        err = launch_wgrad_mfma(wp, e->math, s);
         if (err == hipSuccess) {
             WgradReduceParams rp; memset(&rp, 0, sizeof(rp));
             rp.partial = e->wg_partial; rp.bias_partial = e->wg_bias_partial; rp.nparts = e->nparts; rp.n_in = n_in; rp.n_g = 1;
