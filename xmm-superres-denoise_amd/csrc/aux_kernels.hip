@@ -151,10 +151,12 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const EdgeWgradParams P
 
 __global__ void edge_wgrad_final_kernel(const float* partial, int nblocks, int mode, float* dw, float* db)
 {
-    const int e = threadIdx.x + blockIdx.x * blockDim.x;
-    if (e >= 321) return;
+    // one 64-lane wave per output element: lane l sums blocks l, l+64, ... then a fixed-order shuffle tree
+    const int e = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partial[(long long)b * 321 + e];
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += (double)partial[(long long)b * 321 + e];
+    for (int k = 32; k > 0; k >>= 1) s += __shfl_down(s, k);
+    if (threadIdx.x != 0) return;
     if (mode == 0) { // conv_first: dW[c][0][tap], db[c]
         if (e < 288) dw[(e & 31) * 9 + (e >> 5)] = (float)s;
         else if (e < 320) db[e - 288] = (float)s;
@@ -197,11 +199,16 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const float* y, const floa
 }
 __global__ void l1_loss_final_kernel(const double* partial, int nblocks, float* loss, double inv_n)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += partial[b];
-        *loss = (float)(s * inv_n);
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) *loss = (float)(red[0] * inv_n);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -418,7 +425,7 @@ hipError_t launch_edge_reduce(const EdgeReduceParams& p, hipStream_t s)
 hipError_t launch_edge_wgrad(const EdgeWgradParams& p, int mode, float* dw, float* db, hipStream_t s)
 {
     hipLaunchKernelGGL(edge_wgrad_kernel, dim3(p.nblocks), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(edge_wgrad_final_kernel, dim3(2), dim3(256), 0, s, p.partial, p.nblocks, mode, dw, db);
+    hipLaunchKernelGGL(edge_wgrad_final_kernel, dim3(321), dim3(64), 0, s, p.partial, p.nblocks, mode, dw, db);
     return hipGetLastError();
 }
 hipError_t launch_clamp_bwd(const float* pre, const float* dy, float* dpre, long long n, hipStream_t s)
@@ -430,7 +437,7 @@ hipError_t launch_l1_loss(const float* y, const float* t, float* dy, double* par
                           long long n, hipStream_t s)
 {
     hipLaunchKernelGGL(l1_loss_kernel, dim3(nblocks), dim3(256), 0, s, y, t, dy, partial, n, 1.0f / (float)n);
-    hipLaunchKernelGGL(l1_loss_final_kernel, dim3(1), dim3(64), 0, s, partial, nblocks, loss, 1.0 / (double)n);
+    hipLaunchKernelGGL(l1_loss_final_kernel, dim3(1), dim3(256), 0, s, partial, nblocks, loss, 1.0 / (double)n);
     return hipGetLastError();
 }
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, long long n, int step, float lr, float b1, float b2,

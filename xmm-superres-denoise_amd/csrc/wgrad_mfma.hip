@@ -354,39 +354,52 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_bf16x3_kernel(const Wgrad
 }
 
 // Fixed-order combination of the per-workgroup partials into the OIHW gradient (state-dict layout).
-__global__ void wgrad_reduce_kernel(const WgradReduceParams R)
+// Block = 1024 threads = 16 waves: wave w sums partials [w*P/16, (w+1)*P/16) of 64 consecutive elements (16 loads in
+// flight per lane), then the 16 wave sums are combined in fixed order through LDS: deterministic and ~20x shorter than a
+// serial 256-term chain per element.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReduceParams R)
 {
+    __shared__ double red[16][64];
     const int total = R.n_g * R.n_in * 9 * 1024;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const long long stride = (long long)R.n_g * R.n_in * 9 * 1024;
+    const int per = (R.nparts + 15) / 16;
+    const int p0 = w * per, p1 = min(R.nparts, p0 + per);
+    double s = 0.0;
     if (e < total) {
+        int p = p0;
+        for (; p + 8 <= p1; p += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = R.partial[(p + u) * stride + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; p < p1; ++p) s += (double)R.partial[p * stride + e];
+    }
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && e < total) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][lane];
         int r = e;
         const int co = r & 31; r >>= 5;
         const int ci = r & 31; r >>= 5;
         const int tap = r % 9; r /= 9;
         const int j = r % R.n_in;
         const int n = r / R.n_in;
-        const long long stride = (long long)R.n_g * R.n_in * 9 * 1024;
-        // fixed summation order (4 interleaved chains, then a fixed combine) with 8 loads in flight
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int p = 0;
-        for (; p + 8 <= R.nparts; p += 8) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = R.partial[(p + u) * stride + e];
-            s0 += (double)v[0] + (double)v[4]; s1 += (double)v[1] + (double)v[5];
-            s2 += (double)v[2] + (double)v[6]; s3 += (double)v[3] + (double)v[7];
-        }
-        for (; p < R.nparts; ++p) s0 += (double)R.partial[p * stride + e];
-        const double s = (s0 + s1) + (s2 + s3);
         const int oc = R.shuffle ? (4 * co + n) : (32 * n + co);
-        R.dw[((long long)oc * R.cin_total + (32 * j + ci)) * 9 + tap] = (float)(s * (double)R.scale);
+        R.dw[((long long)oc * R.cin_total + (32 * j + ci)) * 9 + tap] = (float)(t * (double)R.scale);
     }
-    if (e < R.n_g * 32) {
-        const int co = e & 31, n = e >> 5;
-        double s = 0.0;
-        for (int p = 0; p < R.nparts; ++p) s += (double)R.bias_partial[((long long)p * R.n_g + n) * 32 + co];
+    // bias: block 0, one wave per 64 (n, co) entries
+    if (blockIdx.x == 0 && threadIdx.x < R.n_g * 32) {
+        const int co = threadIdx.x & 31, n = threadIdx.x >> 5;
+        double t = 0.0;
+        for (int p = 0; p < R.nparts; ++p) t += (double)R.bias_partial[((long long)p * R.n_g + n) * 32 + co];
         const int oc = R.shuffle ? (4 * co + n) : (32 * n + co);
-        R.db[oc] = (float)(s * (double)R.scale);
+        R.db[oc] = (float)(t * (double)R.scale);
     }
 }
 
@@ -411,7 +424,7 @@ hipError_t launch_wgrad_mfma(const WgradParams& p, int split, hipStream_t stream
 hipError_t launch_wgrad_reduce(const WgradReduceParams& r, hipStream_t stream)
 {
     const int total = r.n_g * r.n_in * 9 * 1024;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, r);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(1024), 0, stream, r);
     return hipGetLastError();
 }
 
