@@ -116,6 +116,8 @@ int xsd_profile_read(xsd_engine* e, int klass, double* total_ms, int64_t* launch
 /* Diagnostic only: accumulated shader-cycle stamps of the conv kernel's phases
  * [0] prologue, [1] prefetch issue, [2] MFMA loop, [3] epilogue, [4] wait+barrier, [5] split+LDS write+barrier, [6] items. */
 int xsd_debug_stamps(xsd_engine* e, int enable, unsigned long long* out8);
+/* Diagnostic only: hipOccupancyMaxActiveBlocksPerMultiprocessor of the split forward conv kernel at a dynamic LDS size. */
+int xsd_debug_occupancy(int lds_bytes);
 
 /* Single-layer entry points used by the kernel-level parity tests (one 3x3 conv over NHWC 32-channel planes).
  * dev_in: [n_in] plane pointers on the host (each plane [B][H][W][32]); w_oihw: device OIHW [32*n_out][32*n_in][3][3]. */

@@ -25,6 +25,8 @@
 // Two step structures share the code:
 //   MULTI_OUT=false : n_in input planes (K-loop), one output chunk          (forward dense convs; dgrad of 32->128)
 //   MULTI_OUT=true  : one input plane staged once, n_out output chunks      (dgrad of dense convs; forward 32->128)
+#include <cstdlib>
+#include "conv_core.h"
 #include "xsd_kernels.h"
 
 namespace xsd {
@@ -54,6 +56,7 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u16x8& hi
     }
 }
 
+constexpr int CONV_LDS_TOTAL = CONV_LDS_BYTES + 5 * 32 * 4; // + bias -> 81,024 B, still 2 workgroups per CU
 constexpr int ROW_BYTES = HALO_W * 128; // 4352 = 17 x 256: every halo row starts on a bank-row boundary
 
 // LDS byte offset of 16-B chunk c (0..7) of halo pixel (hy, hx).  The XOR swizzle depends on hx only, so a tap shift
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
         const int hy = p / HALO_W, hx = p - hy * HALO_W;
         const int gy = T.y0 - 1 + hy, gx = T.x0 - 1 + hx;
         const bool ok = (slot < (SPLIT ? SP_SLOTS : IN_SLOTS)) && (gy >= 0) && (gy < P.H) && (gx >= 0) && (gx < P.W);
-        return ok ? gy * rs + gx * ps + sub : -1;
+        return (ok && !(P.ablate & 1)) ? gy * rs + gx * ps + sub : -1;
     };
     int goff[SPLIT ? NR : 1]; // split mode keeps the 6 offsets in registers; fp32 mode (11 slots) recomputes them
     auto tile_offsets = [&](const TileXY& T, int rs, int ps) {
@@ -171,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
     };
     auto load_w = [&](int s) {
         const f32x4* src = reinterpret_cast<const f32x4*>(P.wpanel + (long long)s * PANEL_FLOATS);
+        if (P.ablate & 2) return;
 #pragma unroll
         for (int r = 0; r < W_ROUNDS; ++r) pw[r] = src[r * 256 + tid];
     };
@@ -182,63 +186,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
     f32x16 acc[2];
     // D = W (rows = output channel) x X (cols = pixel): lane = (pixel l31, half h); register i holds channel
     // co(i) = (i&3) + 8*(i>>2) + 4h, i.e. four float4 groups q = 0..3 at channels 8q + 4h .. +3.
+    // bias goes through LDS: a global load issued after the prefetch would make its consumer wait for every older
+    // VMEM op (vmcnt retires in order) and serialise the prefetch in front of the MFMAs.
+    float* bias_lds = reinterpret_cast<float*>(smem + CONV_LDS_BYTES);
+    if (tid < 160) bias_lds[tid] = (P.bias && tid < 32 * (MULTI_OUT ? P.n_out : 1)) ? P.bias[tid] : 0.f;
     auto init_acc = [&](int j) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (P.bias) bv = *reinterpret_cast<const f32x4*>(P.bias + j * 32 + 8 * q + 4 * h);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + j * 32 + 8 * q + 4 * h);
 #pragma unroll
             for (int t = 0; t < 4; ++t) { acc[0][4 * q + t] = bv[t]; acc[1][4 * q + t] = bv[t]; }
         }
     };
 
     const char* wl = w_lds + lane * 16;
-    auto compute = [&]() {
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap - dy * 3;
-            if constexpr (!SPLIT) {
-                f32x4 bf[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f32x4*>(wl + (tap * 4 + j) * 1024);
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    f32x4 af[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        af[j] = *reinterpret_cast<const f32x4*>(in_lds + abase[dx][j] + (r + dy) * ROW_BYTES);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][q], af[j][q], acc[r], 0, 0, 0);
-                }
-            } else {
-                // weight fragments [tap][kstep s2][hi|lo][lane]: 8 bf16 = input channels 16*s2 + 8h + 0..7, column co = l31
-                bf16x8 bh[2], bl[2];
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    bh[s2] = *reinterpret_cast<const bf16x8*>(wl + ((tap * 2 + s2) * 2 + 0) * 1024);
-                    bl[s2] = *reinterpret_cast<const bf16x8*>(wl + ((tap * 2 + s2) * 2 + 1) * 1024);
-                }
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    bf16x8 ah[2], al[2];
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        ah[s2] = *reinterpret_cast<const bf16x8*>(in_lds + abase[dx][s2] + (r + dy) * ROW_BYTES);
-                        al[s2] = *reinterpret_cast<const bf16x8*>(in_lds + abase[dx][2 + s2] + (r + dy) * ROW_BYTES);
-                    }
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s2], al[s2], acc[r], 0, 0, 0);
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[s2], ah[s2], acc[r], 0, 0, 0);
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s2], ah[s2], acc[r], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    };
+    auto compute = [&]() { if (!(P.ablate & 8)) conv_compute<SPLIT, ROW_BYTES>(in_lds, wl, abase, acc); };
 
     // Epilogue: each lane owns one pixel and 16 channels as four float4 groups -> 16-B loads/stores; lanes l and l+32
     // cover adjacent 16-B chunks, so every store instruction writes 32 x 32 contiguous bytes.
@@ -247,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
         float* dst = o.p + (long long)T.b * o.bs;
         const long long sb = (long long)T.b * P.std_bs;
         const int x = T.x0 + l31;
-        if (x >= P.W) return;
+        if (x >= P.W || (P.ablate & 4)) return;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int y = T.y0 + wv * 2 + r;
@@ -335,7 +297,7 @@ template <bool M, bool S>
 static hipError_t set_lds()
 {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<M, S>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES);
+                               hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_TOTAL);
 }
 static hipError_t set_lds_once()
 {
@@ -363,16 +325,27 @@ hipError_t launch_conv3x3_mfma(const ConvParams& p, int split, hipStream_t strea
         if (!cached) { hipDeviceProp_t prop; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached = prop.multiProcessorCount; else cached = 256; }
         ncu = cached;
     }
-    const int resident = 2 * ncu; // 2 workgroups per CU (LDS 80,384 B each)
+    static int wgpc = 0;
+    if (!wgpc) { const char* e = getenv("XSD_WGPC"); wgpc = e ? atoi(e) : 2; if (wgpc < 1) wgpc = 2; }
+    const int resident = wgpc * ncu; // 2 workgroups per CU (LDS 81,024 B each)
     const dim3 g(ntiles < resident ? ntiles : resident), b(256);
     if (p.n_out > 1) {
-        if (split) hipLaunchKernelGGL((conv3x3_mfma_kernel<true, true>), g, b, CONV_LDS_BYTES, stream, p);
-        else hipLaunchKernelGGL((conv3x3_mfma_kernel<true, false>), g, b, CONV_LDS_BYTES, stream, p);
+        if (split) hipLaunchKernelGGL((conv3x3_mfma_kernel<true, true>), g, b, CONV_LDS_TOTAL, stream, p);
+        else hipLaunchKernelGGL((conv3x3_mfma_kernel<true, false>), g, b, CONV_LDS_TOTAL, stream, p);
     } else {
-        if (split) hipLaunchKernelGGL((conv3x3_mfma_kernel<false, true>), g, b, CONV_LDS_BYTES, stream, p);
-        else hipLaunchKernelGGL((conv3x3_mfma_kernel<false, false>), g, b, CONV_LDS_BYTES, stream, p);
+        if (split) hipLaunchKernelGGL((conv3x3_mfma_kernel<false, true>), g, b, CONV_LDS_TOTAL, stream, p);
+        else hipLaunchKernelGGL((conv3x3_mfma_kernel<false, false>), g, b, CONV_LDS_TOTAL, stream, p);
     }
     return hipGetLastError();
+}
+
+// diagnostic: occupancy API answer for the split forward kernel at a given dynamic LDS size
+int debug_conv_occupancy(int lds_bytes)
+{
+    int n = -1;
+    if (set_lds_once() != hipSuccess) return -2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&conv3x3_mfma_kernel<false, true>), 256, lds_bytes) != hipSuccess) return -3;
+    return n;
 }
 
 } // namespace xsd

@@ -16,6 +16,7 @@ struct MaskPadParams {
 };
 
 hipError_t launch_conv3x3_mfma(const ConvParams& p, int split, hipStream_t stream);
+hipError_t launch_conv3x3_big(const ConvParams& p, int split, hipStream_t stream);
 hipError_t launch_wgrad_mfma(const WgradParams& p, int split, hipStream_t stream);
 hipError_t launch_wgrad_reduce(const WgradReduceParams& r, hipStream_t stream);
 hipError_t launch_edge_expand(const EdgeExpandParams& p, hipStream_t s);

@@ -25,6 +25,7 @@
 using namespace xsd;
 
 namespace xsd {
+int debug_conv_occupancy(int lds_bytes);
 hipError_t launch_pack_shuffle_bias(const float* b, float* out, hipStream_t s);
 }
 
@@ -70,6 +71,8 @@ struct xsd_engine {
     float* pk_bwd = nullptr;
     unsigned short* pk_fwd_s = nullptr; // bf16x3 (hi|lo) panels, same byte size / offsets as pk_fwd / pk_bwd
     unsigned short* pk_bwd_s = nullptr;
+    int ablate = 0;            // diagnostic (env XSD_ABLATE)
+    int big = 0;               // conv structure: 0 = 8x32 tile, 2 WG/CU; 1 = 16x32 tile, 1 WG/CU, LDS-DMA weight ring
     int math = 0;              // 0 = exact fp32 MFMA, 1 = bf16x3 split MFMA (conv forward + input-gradient)
     float* pk_edge = nullptr; // first_fwd, first_bwd, last_fwd, last_bwd (288 each)
     float* pk_sbias = nullptr;
@@ -218,7 +221,8 @@ struct Builder {
         return [eng, p, bias_from_params, bias_off, flop, bytes](hipStream_t s) mutable {
             if (bias_from_params) p.bias = eng->params + bias_off;
             p.dbg = eng->dbg;
-            return prof_launch(eng, 0, flop, bytes, s, [&]() { return launch_conv3x3_mfma(p, eng->math, s); });
+            p.ablate = eng->ablate;
+            return prof_launch(eng, 0, flop, bytes, s, [&]() { return eng->big ? launch_conv3x3_big(p, eng->math, s) : launch_conv3x3_mfma(p, eng->math, s); });
         };
     }
     // wgrad + fixed-order reduce into the flat gradient vector
@@ -509,6 +513,8 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(XSD_ERR_HIP, "no HIP device available");
     xsd_engine* e = new xsd_engine();
     e->cfg = *cfg;
+    if (const char* m = getenv("XSD_ABLATE")) e->ablate = atoi(m);
+    if (const char* m = getenv("XSD_CONV")) e->big = strcmp(m, "big") == 0 ? 1 : 0;
     if (const char* m = getenv("XSD_MATH")) e->math = (strcmp(m, "bf16x3") == 0 || strcmp(m, "1") == 0) ? 1 : 0;
     const int blocks = cfg->num_res_blocks, nup = cfg->kind == XSD_KIND_SR ? cfg->num_upsample : 0;
     long long off = 0, pk = 0, sb = 0;
@@ -694,6 +700,8 @@ int xsd_image_upsample(const float* dev_in, float* dev_out, int N, int H, int W,
     return XSD_OK;
 }
 
+int xsd_debug_occupancy(int lds_bytes) { return xsd::debug_conv_occupancy(lds_bytes); }
+
 // diagnostic: accumulate shader-cycle stamps of the conv kernel's phases (enable != 0 allocates/zeroes; read copies out)
 int xsd_debug_stamps(xsd_engine* e, int enable, unsigned long long* out8)
 {
@@ -763,7 +771,7 @@ int xsd_test_conv3x3(xsd_engine* e, const float* const* in_planes, int n_in, con
     p.n_in = n_in; p.n_out = n_out; p.wpanel = fwd; p.bias = dev_bias;
     for (int i = 0; i < n_in; ++i) p.in[i] = b.std_in(in_planes[i], 0);
     for (int j = 0; j < n_out; ++j) { b.std_out(p.out[j], out_planes[j], 0); p.out[j].slope = slope; }
-    hipError_t err = launch_conv3x3_mfma(p, e->math, s);
+    hipError_t err = e->big ? launch_conv3x3_big(p, e->math, s) : launch_conv3x3_mfma(p, e->math, s);
     hipStreamSynchronize(s);
     hipFree(fwd); hipFree(bwd);
     if (err != hipSuccess) return fail(XSD_ERR_HIP, "conv launch: %s", hipGetErrorString(err));
@@ -782,7 +790,7 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
     ConvParams p = b.conv_base(0);
     p.n_in = 1; p.n_out = n_in; p.wpanel = bwd; p.in[0] = b.std_in(dev_g_plane, 0);
     for (int j = 0; j < n_in; ++j) b.std_out(p.out[j], dx_planes[j], 0);
-    hipError_t err = launch_conv3x3_mfma(p, e->math, s);
+    hipError_t err = e->big ? launch_conv3x3_big(p, e->math, s) : launch_conv3x3_mfma(p, e->math, s);
     if (err == hipSuccess) {
         WgradParams wp; memset(&wp, 0, sizeof(wp));
         wp.B = B; wp.H = H; wp.W = W; wp.tilesX = p.tilesX; wp.tilesY = p.tilesY; wp.n_in = n_in; wp.n_g = 1; wp.nparts = e->nparts;

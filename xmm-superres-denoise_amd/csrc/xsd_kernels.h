@@ -52,6 +52,8 @@ struct ConvParams {
     PlaneIn in[5];
     const float* wpanel; // [n_out][n_in] panels (one of the two is 1), PANEL_FLOATS each
     const float* bias;   // [n_out*32] or nullptr
+    int ablate;          // diagnostic ablation bits (0 in production): 1 skip input loads, 2 skip weight loads, 4 skip stores, 8 skip MFMA loop
+    int pad_;
     unsigned long long* dbg; // diagnostic phase stamps (null in production): [grid][8] accumulated shader cycles
     OutDesc out[5];
 };
