@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="dn_train", choices=["dn_train", "sr_train", "dn_fwd", "sr_fwd"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 32 at N=1, 16 at N>1; sr_fwd: 16)")
-    ap.add_argument("--math", default=os.environ.get("XSD_MATH", "fp32"), choices=["fp32", "bf16x3"],
+    ap.add_argument("--math", default=os.environ.get("XSD_MATH", "fp32"), choices=["fp32", "bf16x3", "bf16x3_p16"],
                     help="MFMA math mode of the conv kernels (include/xsd.h: xsd_set_math)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")

@@ -59,7 +59,11 @@ int64_t xsd_param_count(const xsd_engine* e);
 /* Math mode of the MFMA convs (forward + input-gradient): 0 = exact fp32 (v_mfma_f32_32x32x2_f32);
  * 1 = "bf16x3": operands split into hi+lo bf16 terms, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
  * accumulation (per-product error <= 3*2^-16; whole-net error ~5e-6 of max, inside the 1e-3 parity tolerance).
- * Default from the environment variable XSD_MATH ("fp32" | "bf16x3").  Changing it invalidates the packed weights. */
+ * 2 = "bf16x3_p16": the same arithmetic, but every feature plane is kept pre-split in HBM (P16 format, csrc/p16.h:
+ * per pixel 32 x bf16 hi | 32 x bf16 lo in accumulator channel order, same 128 B) so tiles move HBM -> LDS by LDS-DMA with
+ * no staging instructions; activations carry 16 significant bits (whole-net error ~5e-6 of max).
+ * Default from the environment variable XSD_MATH ("fp32" | "bf16x3" | "bf16x3_p16").  Changing it invalidates the
+ * packed weights and the plan. */
 int xsd_set_math(xsd_engine* e, int mode);
 int xsd_get_math(const xsd_engine* e);
 

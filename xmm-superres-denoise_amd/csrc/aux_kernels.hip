@@ -1,6 +1,7 @@
 // aux_kernels.hip -- the HBM-bound kernels around the MFMA convs: edge layers (Cin=1 / Cout=1), loss, Adam,
 // weight repack, and the input transforms (detector mask, centred pad, Normalize, ImageUpsample).
 // Each kernel cites the reference code it replaces.
+#include "p16.h"
 #include "xsd_kernels.h"
 #include "xsd_aux.h"
 
@@ -38,12 +39,15 @@ __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams
                 v += sv * w4;
             }
         }
+        const int ppos = 16 * (q & 1) + 4 * (q >> 1); // P16 position of channel 4q (p16.h)
         if (P.mask) {
-            const f32x4 m = *reinterpret_cast<const f32x4*>(P.mask + pix * 32 + q * 4);
+            const f32x4 m = P.p16 ? p16_load4(reinterpret_cast<const char*>(P.mask + pix * 32), ppos)
+                                  : *reinterpret_cast<const f32x4*>(P.mask + pix * 32 + q * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : v[i] * P.mslope;
         }
-        *reinterpret_cast<f32x4*>(P.out + pix * 32 + q * 4) = v;
+        if (P.p16) p16_store4(reinterpret_cast<char*>(P.out + pix * 32), ppos, v);
+        else *reinterpret_cast<f32x4*>(P.out + pix * 32 + q * 4) = v;
     }
 }
 
@@ -73,7 +77,9 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeReduceParams
             for (int tap = 0; tap < 9; ++tap) {
                 const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
                 if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
-                    const f32x4 fv = *reinterpret_cast<const f32x4*>(fb + ((long long)yy * P.W + xx) * 32 + q * 4);
+                    const float* pxp = fb + ((long long)yy * P.W + xx) * 32;
+                    const f32x4 fv = P.p16 ? p16_load4(reinterpret_cast<const char*>(pxp), 16 * (q & 1) + 4 * (q >> 1))
+                                           : *reinterpret_cast<const f32x4*>(pxp + q * 4);
                     const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wl[tap * 32 + q * 4]);
                     acc += fv[0] * w4[0] + fv[1] * w4[1] + fv[2] * w4[2] + fv[3] * w4[3];
                 }
@@ -114,7 +120,8 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const EdgeWgradParams P
         const long long r = pix / P.W;
         const int y = (int)(r % P.H);
         const float* sb = P.s + (r - y) * P.W;
-        const f32x4 fv = *reinterpret_cast<const f32x4*>(P.f + pix * 32 + q * 4);
+        const f32x4 fv = P.p16 ? p16_load4(reinterpret_cast<const char*>(P.f + pix * 32), 16 * (q & 1) + 4 * (q >> 1))
+                               : *reinterpret_cast<const f32x4*>(P.f + pix * 32 + q * 4);
         bs += fv;
         if (q == 0) ss += sb[(long long)y * P.W + x];
 #pragma unroll
@@ -300,6 +307,62 @@ __global__ void pack_weights_split_kernel(const float* params, const PackDesc* d
     }
 }
 
+// math mode 2 panels (conv3x3_p16.hip): per panel two 18,432-B halves [s2][tap][hi|lo][lane = h*32 + m][j]; row m is
+// the output channel, the k index of element j is input POSITION 16*s2 + 8h + j of a P16 plane = channel p16_ch(pos).
+__global__ void pack_weights_p16_kernel(const float* params, const PackDesc* descs, unsigned short* fwd, unsigned short* bwd)
+{
+    const PackDesc d = descs[blockIdx.y];
+    const int ns = d.cin / 32, nn = d.cout / 32;
+    const int PE = 2 * PANEL_FLOATS;
+    const long long total = (long long)ns * nn * PE;
+    const float* W = params + d.src_w;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        int r = (int)(e % PE);
+        const int panel = (int)(e / PE);
+        const int j = r & 7; r >>= 3;
+        const int m = r & 31; r >>= 5;
+        const int h = r & 1; r >>= 1;
+        const int part = r & 1; r >>= 1;
+        const int tap = r % 9;
+        const int s2 = r / 9;
+        const int kch = p16_ch(16 * s2 + 8 * h + j);
+        float wf, wb;
+        {
+            const int n = panel / ns, s = panel % ns;
+            const int oc = d.shuffle ? (4 * m + n) : (32 * n + m);
+            wf = W[((long long)oc * d.cin + 32 * s + kch) * 9 + tap];
+        }
+        {
+            const int s = panel / nn, n = panel % nn;
+            const int oc = d.shuffle ? (4 * kch + n) : (32 * n + kch);
+            wb = W[((long long)oc * d.cin + 32 * s + m) * 9 + (8 - tap)];
+        }
+        const __bf16 fh = (__bf16)wf, bh = (__bf16)wb;
+        const __bf16 fl = (__bf16)(wf - (float)fh), bl = (__bf16)(wb - (float)bh);
+        fwd[2 * d.dst_fwd + e] = __builtin_bit_cast(unsigned short, part ? fl : fh);
+        bwd[2 * d.dst_bwd + e] = __builtin_bit_cast(unsigned short, part ? bl : bh);
+    }
+}
+
+// fp32 plane <-> P16 plane (test hooks / debugging): thread = (pixel, 4-channel quad)
+__global__ void plane_to_p16_kernel(const float* in, float* out, long long npix)
+{
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < npix * 8; g += (long long)gridDim.x * blockDim.x) {
+        const long long pix = g >> 3;
+        const int q = (int)(g & 7);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + pix * 32 + q * 4);
+        p16_store4(reinterpret_cast<char*>(out + pix * 32), 16 * (q & 1) + 4 * (q >> 1), v);
+    }
+}
+__global__ void plane_from_p16_kernel(const float* in, float* out, long long npix)
+{
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < npix * 8; g += (long long)gridDim.x * blockDim.x) {
+        const long long pix = g >> 3;
+        const int q = (int)(g & 7);
+        *reinterpret_cast<f32x4*>(out + pix * 32 + q * 4) = p16_load4(reinterpret_cast<const char*>(in + pix * 32), 16 * (q & 1) + 4 * (q >> 1));
+    }
+}
+
 // edge-layer weights: conv_first W[c][0][tap] -> [tap][c] (forward) ; conv_last W[0][c][tap] -> [tap][c] (forward)
 // and the flipped forms used by their input-gradients.
 __global__ void pack_edge_kernel(const float* w_first, const float* w_last, float* first_fwd, float* first_bwd,
@@ -400,6 +463,32 @@ __global__ void upsample_nearest_kernel(const float* in, float* out, int N, int 
     }
 }
 
+// diagnostic: residency census.  Every workgroup sleeps ~`us` microseconds; with R workgroups resident per CU a grid of
+// G workgroups takes ceil(G / (R * CUs)) * us.
+__global__ void sleep_kernel(int us, int* sink)
+{
+    extern __shared__ char dyn[];
+    const long long t0 = wall_clock64(); // 100 MHz
+    while (wall_clock64() - t0 < (long long)us * 100) __builtin_amdgcn_s_sleep(32);
+    if (us < 0) sink[0] = dyn[threadIdx.x];
+}
+float debug_residency_ms(int grid, int threads, int lds_bytes, int us)
+{
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&sleep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL(sleep_kernel, dim3(grid), dim3(threads), lds_bytes, 0, 10, nullptr);
+    hipDeviceSynchronize();
+    hipEventRecord(a, 0);
+    hipLaunchKernelGGL(sleep_kernel, dim3(grid), dim3(threads), lds_bytes, 0, us, nullptr);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, a, b);
+    hipEventDestroy(a); hipEventDestroy(b);
+    return ms;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------------------------
@@ -458,6 +547,18 @@ hipError_t launch_pack_weights_split(const float* params, const PackDesc* descs_
                                      unsigned short* bwd, hipStream_t s)
 {
     hipLaunchKernelGGL(pack_weights_split_kernel, dim3(72, ndesc), dim3(256), 0, s, params, descs_dev, fwd, bwd);
+    return hipGetLastError();
+}
+hipError_t launch_pack_weights_p16(const float* params, const PackDesc* descs_dev, int ndesc, unsigned short* fwd,
+                                   unsigned short* bwd, hipStream_t s)
+{
+    hipLaunchKernelGGL(pack_weights_p16_kernel, dim3(72, ndesc), dim3(256), 0, s, params, descs_dev, fwd, bwd);
+    return hipGetLastError();
+}
+hipError_t launch_plane_convert(const float* in, float* out, long long npix, int to_p16, hipStream_t s)
+{
+    if (to_p16) hipLaunchKernelGGL(plane_to_p16_kernel, dim3(grid_for(npix * 8, 256)), dim3(256), 0, s, in, out, npix);
+    else hipLaunchKernelGGL(plane_from_p16_kernel, dim3(grid_for(npix * 8, 256)), dim3(256), 0, s, in, out, npix);
     return hipGetLastError();
 }
 hipError_t launch_pack_edge(const float* w_first, const float* w_last, float* ff, float* fb, float* lf, float* lb,

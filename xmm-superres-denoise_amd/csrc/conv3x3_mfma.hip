@@ -239,6 +239,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
     };
 
     if (items <= 0) return;
+    // stagger: the two workgroups that share a CU run the same program; started together they phase-lock (both in the
+    // MFMA loop, then both staging).  Delay the second half of the grid by about half a step (diagnostic knob bit 16+).
+    if ((P.ablate >> 4) && (int)blockIdx.x >= (G >> 1)) {
+        for (int q = 0; q < (P.ablate >> 4); ++q) __builtin_amdgcn_s_sleep(127);
+    }
     // diagnostic stamps (P.dbg != null only in profiling builds of the HOST side; never in timed runs)
     unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t0 = 0;

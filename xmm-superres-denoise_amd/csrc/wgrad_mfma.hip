@@ -9,6 +9,7 @@
 // of them; wave w owns row w of each tile (32 pixels = 16 MFMA k-steps of 2 pixels).  Partial sums are written once
 // per workgroup ([nparts][n][j][9][32][32]) and combined in a fixed order by wgrad_reduce_kernel, so the result is
 // bitwise reproducible (no float atomics).
+#include "p16.h"
 #include "xsd_kernels.h"
 
 namespace xsd {
@@ -390,15 +391,17 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReducePar
         const int tap = r % 9; r /= 9;
         const int j = r % R.n_in;
         const int n = r / R.n_in;
-        const int oc = R.shuffle ? (4 * co + n) : (32 * n + co);
-        R.dw[((long long)oc * R.cin_total + (32 * j + ci)) * 9 + tap] = (float)(t * (double)R.scale);
+        const int cch = R.p16 ? p16_ch(co) : co, ich = R.p16 ? p16_ch(ci) : ci; // P16 kernel: rows/cols are positions
+        const int oc = R.shuffle ? (4 * cch + n) : (32 * n + cch);
+        R.dw[((long long)oc * R.cin_total + (32 * j + ich)) * 9 + tap] = (float)(t * (double)R.scale);
     }
     // bias: block 0, one wave per 64 (n, co) entries
     if (blockIdx.x == 0 && threadIdx.x < R.n_g * 32) {
         const int co = threadIdx.x & 31, n = threadIdx.x >> 5;
         double t = 0.0;
         for (int p = 0; p < R.nparts; ++p) t += (double)R.bias_partial[((long long)p * R.n_g + n) * 32 + co];
-        const int oc = R.shuffle ? (4 * co + n) : (32 * n + co);
+        const int cch = R.p16 ? p16_ch(co) : co;
+        const int oc = R.shuffle ? (4 * cch + n) : (32 * n + cch);
         R.db[oc] = (float)(t * (double)R.scale);
     }
 }

@@ -31,6 +31,11 @@ hipError_t launch_pack_weights(const float* params, const PackDesc* descs_dev, i
                                hipStream_t s);
 hipError_t launch_pack_weights_split(const float* params, const PackDesc* descs_dev, int ndesc, unsigned short* fwd,
                                      unsigned short* bwd, hipStream_t s);
+hipError_t launch_pack_weights_p16(const float* params, const PackDesc* descs_dev, int ndesc, unsigned short* fwd,
+                                   unsigned short* bwd, hipStream_t s);
+hipError_t launch_plane_convert(const float* in, float* out, long long npix, int to_p16, hipStream_t s);
+hipError_t launch_conv3x3_p16(const ConvParams& p, hipStream_t stream);
+hipError_t launch_wgrad_p16(const WgradParams& p, hipStream_t stream);
 hipError_t launch_pack_edge(const float* w_first, const float* w_last, float* ff, float* fb, float* lf, float* lb,
                             hipStream_t s);
 hipError_t launch_mask_pad_normalize(const MaskPadParams& p, hipStream_t s);

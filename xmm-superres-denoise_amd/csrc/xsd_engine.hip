@@ -26,6 +26,7 @@ using namespace xsd;
 
 namespace xsd {
 int debug_conv_occupancy(int lds_bytes);
+float debug_residency_ms(int grid, int threads, int lds_bytes, int us);
 hipError_t launch_pack_shuffle_bias(const float* b, float* out, hipStream_t s);
 }
 
@@ -100,6 +101,7 @@ struct xsd_engine {
     const float* b_dy = nullptr;
     float* b_dx = nullptr;
     float* b_grads = nullptr;
+    void* zero_page = nullptr;         // 256 B of zeros (math mode 2 DMA source for padding)
     unsigned long long* dbg = nullptr; // conv phase stamps (diagnostic)
     // profiling
     bool prof = false;
@@ -222,7 +224,8 @@ struct Builder {
             if (bias_from_params) p.bias = eng->params + bias_off;
             p.dbg = eng->dbg;
             p.ablate = eng->ablate;
-            return prof_launch(eng, 0, flop, bytes, s, [&]() { return eng->big ? launch_conv3x3_big(p, eng->math, s) : launch_conv3x3_mfma(p, eng->math, s); });
+            p.zero = eng->zero_page;
+            return prof_launch(eng, 0, flop, bytes, s, [&]() { return eng->math == 2 ? launch_conv3x3_p16(p, s) : eng->big ? launch_conv3x3_big(p, eng->math, s) : launch_conv3x3_mfma(p, eng->math, s); });
         };
     }
     // wgrad + fixed-order reduce into the flat gradient vector
@@ -249,7 +252,8 @@ struct Builder {
             wp.partial = eng->wg_partial; wp.bias_partial = eng->wg_bias_partial;
             rp.partial = eng->wg_partial; rp.bias_partial = eng->wg_bias_partial;
             rp.dw = eng->b_grads + w_off; rp.db = eng->b_grads + b_off;
-            hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return launch_wgrad_mfma(wp, eng->math, s); });
+            wp.zero = eng->zero_page; rp.p16 = eng->math == 2;
+            hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return eng->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, eng->math, s); });
             if (err != hipSuccess) return err;
             return launch_wgrad_reduce(rp, s);
         });
@@ -273,7 +277,7 @@ struct Builder {
         // ---- forward ------------------------------------------------------------------------------------------
         float* fea = alloc(0);
         { // conv_first (generator_rrdb.py:67)
-            EdgeExpandParams p; memset(&p, 0, sizeof(p));
+            EdgeExpandParams p; memset(&p, 0, sizeof(p)); p.p16 = e->math == 2;
             p.B = B; p.H = H; p.W = W; p.out = fea; p.w = e->pk_edge + 0; p.mslope = 1.f;
             const long long boff = e->first_b;
             F.push_back([eng, p, boff](hipStream_t s) mutable { p.s = eng->b_x; p.bias = eng->params + boff; return launch_edge_expand(p, s); });
@@ -346,7 +350,7 @@ struct Builder {
         }
         pre = train ? alloc1(lo) : nullptr;
         { // conv_last (+x for DN) + clamp, clamp (generator_rrdb.py:107-108,132-135; model.py:49)
-            EdgeReduceParams p; memset(&p, 0, sizeof(p));
+            EdgeReduceParams p; memset(&p, 0, sizeof(p)); p.p16 = e->math == 2;
             p.B = B; p.H = H << lo; p.W = W << lo; p.f = sr ? H1 : T; p.w = e->pk_edge + 2 * 288; p.pre = pre; p.clamp01 = 1;
             const long long boff = e->last_b;
             F.push_back([eng, p, boff, sr](hipStream_t s) mutable {
@@ -363,7 +367,7 @@ struct Builder {
             const long long npx = (long long)B * (H << lo) * (W << lo);
             S.push_back([eng, pre, dpre, npx](hipStream_t s) { return launch_clamp_bwd(pre, eng->b_dy, dpre, npx, s); });
             { // conv_last weight grad
-                EdgeWgradParams p; memset(&p, 0, sizeof(p));
+                EdgeWgradParams p; memset(&p, 0, sizeof(p)); p.p16 = e->math == 2;
                 p.B = B; p.H = H << lo; p.W = W << lo; p.f = sr ? H1 : T; p.s = dpre; p.nblocks = 512;
                 const long long wo = e->last_w, bo = e->last_b;
                 S.push_back([eng, p, wo, bo](hipStream_t s) mutable {
@@ -371,13 +375,13 @@ struct Builder {
                 });
             }
             if (!sr) {
-                EdgeExpandParams p; memset(&p, 0, sizeof(p));
+                EdgeExpandParams p; memset(&p, 0, sizeof(p)); p.p16 = e->math == 2;
                 p.B = B; p.H = H; p.W = W; p.s = dpre; p.w = e->pk_edge + 3 * 288; p.out = dT; p.mslope = 1.f;
                 S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
             } else {
                 float* GH = alloc(lo);
                 { // d(H1) masked by lrelu'(0.2)
-                    EdgeExpandParams p; memset(&p, 0, sizeof(p));
+                    EdgeExpandParams p; memset(&p, 0, sizeof(p)); p.p16 = e->math == 2;
                     p.B = B; p.H = H << lo; p.W = W << lo; p.s = dpre; p.w = e->pk_edge + 3 * 288; p.out = GH; p.mask = H1; p.mslope = 0.2f;
                     S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
                 }
@@ -457,13 +461,13 @@ struct Builder {
         { // last stage: conv_first weight grad and (optionally) dx
             std::vector<Launch>& S = e->bwd_stages[blocks + 1];
             float* dFea = dR; // when blocks == 0 this is d(rrdb out) and needs + dT; blocks >= 1 is enforced at create
-            EdgeWgradParams p; memset(&p, 0, sizeof(p));
+            EdgeWgradParams p; memset(&p, 0, sizeof(p)); p.p16 = e->math == 2;
             p.B = B; p.H = H; p.W = W; p.f = dFea; p.nblocks = 512;
             const long long wo = e->first_w, bo = e->first_b;
             S.push_back([eng, p, wo, bo](hipStream_t s) mutable {
                 p.s = eng->b_x; p.partial = eng->edge_partial; return launch_edge_wgrad(p, 0, eng->b_grads + wo, eng->b_grads + bo, s);
             });
-            EdgeReduceParams q; memset(&q, 0, sizeof(q));
+            EdgeReduceParams q; memset(&q, 0, sizeof(q)); q.p16 = e->math == 2;
             q.B = B; q.H = H; q.W = W; q.f = dFea; q.w = e->pk_edge + 1 * 288; q.clamp01 = 0;
             const float* skipg = sr ? nullptr : dpre;
             S.push_back([eng, q, skipg](hipStream_t s) mutable {
@@ -515,7 +519,7 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     e->cfg = *cfg;
     if (const char* m = getenv("XSD_ABLATE")) e->ablate = atoi(m);
     if (const char* m = getenv("XSD_CONV")) e->big = strcmp(m, "big") == 0 ? 1 : 0;
-    if (const char* m = getenv("XSD_MATH")) e->math = (strcmp(m, "bf16x3") == 0 || strcmp(m, "1") == 0) ? 1 : 0;
+    if (const char* m = getenv("XSD_MATH")) e->math = (strcmp(m, "bf16x3_p16") == 0 || strcmp(m, "2") == 0) ? 2 : (strcmp(m, "bf16x3") == 0 || strcmp(m, "1") == 0) ? 1 : 0;
     const int blocks = cfg->num_res_blocks, nup = cfg->kind == XSD_KIND_SR ? cfg->num_upsample : 0;
     long long off = 0, pk = 0, sb = 0;
     take_conv(off, 32, 1, e->first_w, e->first_b);
@@ -552,6 +556,8 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     CK(hipMalloc((void**)&e->pk_bwd, sizeof(float) * pk));
     CK(hipMalloc((void**)&e->pk_fwd_s, sizeof(float) * pk));
     CK(hipMalloc((void**)&e->pk_bwd_s, sizeof(float) * pk));
+    CK(hipMalloc((void**)&e->zero_page, 256));
+    CK(hipMemset(e->zero_page, 0, 256));
     CK(hipMalloc((void**)&e->pk_edge, sizeof(float) * 4 * 288));
     CK(hipMalloc((void**)&e->pk_sbias, sizeof(float) * (sb ? sb : 1)));
     CK(hipMalloc((void**)&e->descs_dev, sizeof(PackDesc) * descs.size()));
@@ -570,7 +576,7 @@ void xsd_destroy(xsd_engine* e)
     if (!e) return;
     hipDeviceSynchronize();
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
-    hipFree(e->pk_fwd); hipFree(e->pk_bwd); hipFree(e->pk_fwd_s); hipFree(e->pk_bwd_s); hipFree(e->pk_edge); hipFree(e->pk_sbias); hipFree(e->descs_dev);
+    hipFree(e->pk_fwd); hipFree(e->pk_bwd); hipFree(e->pk_fwd_s); hipFree(e->pk_bwd_s); hipFree(e->zero_page); hipFree(e->pk_edge); hipFree(e->pk_sbias); hipFree(e->descs_dev);
     hipFree(e->wg_partial); hipFree(e->wg_bias_partial); hipFree(e->edge_partial); hipFree(e->loss_partial);
     hipFree(e->ws);
     delete e;
@@ -580,7 +586,7 @@ int64_t xsd_param_count(const xsd_engine* e) { return e ? e->nparams : 0; }
 
 int xsd_set_math(xsd_engine* e, int mode)
 {
-    if (!e || (mode != 0 && mode != 1)) return fail(XSD_ERR_ARG, "math mode must be 0 (fp32) or 1 (bf16x3)");
+    if (!e || mode < 0 || mode > 2) return fail(XSD_ERR_ARG, "math mode must be 0 (fp32), 1 (bf16x3) or 2 (bf16x3 over P16 planes)");
     if (mode != e->math) { e->math = mode; e->packed = false; e->pB = 0; e->ptrain = -1; e->fwd_saved = false; }
     return XSD_OK;
 }
@@ -591,7 +597,9 @@ int xsd_pack_weights(xsd_engine* e, const float* dev_params, void* stream)
     if (!e || !dev_params) return fail(XSD_ERR_ARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
     e->params = dev_params;
-    if (e->math)
+    if (e->math == 2)
+        HIPCHK(launch_pack_weights_p16(dev_params, e->descs_dev, e->ndesc, e->pk_fwd_s, e->pk_bwd_s, s));
+    else if (e->math == 1)
         HIPCHK(launch_pack_weights_split(dev_params, e->descs_dev, e->ndesc, e->pk_fwd_s, e->pk_bwd_s, s));
     else
         HIPCHK(launch_pack_weights(dev_params, e->descs_dev, e->ndesc, e->pk_fwd, e->pk_bwd, s));
@@ -701,6 +709,7 @@ int xsd_image_upsample(const float* dev_in, float* dev_out, int N, int H, int W,
 }
 
 int xsd_debug_occupancy(int lds_bytes) { return xsd::debug_conv_occupancy(lds_bytes); }
+float xsd_debug_residency_ms(int grid, int threads, int lds_bytes, int us) { return xsd::debug_residency_ms(grid, threads, lds_bytes, us); }
 
 // diagnostic: accumulate shader-cycle stamps of the conv kernel's phases (enable != 0 allocates/zeroes; read copies out)
 int xsd_debug_stamps(xsd_engine* e, int enable, unsigned long long* out8)
@@ -751,11 +760,26 @@ static int pack_single(const float* dev_w, int cout, int cin, float** fwd, float
     HIPCHK(hipMalloc((void**)bwd, sizeof(float) * n));
     HIPCHK(hipMalloc((void**)&dd, sizeof(PackDesc)));
     HIPCHK(hipMemcpy(dd, &d, sizeof(d), hipMemcpyHostToDevice));
-    if (math) HIPCHK(launch_pack_weights_split(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
+    if (math == 2) HIPCHK(launch_pack_weights_p16(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
+    else if (math == 1) HIPCHK(launch_pack_weights_split(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
     else HIPCHK(launch_pack_weights(dev_w, dd, 1, *fwd, *bwd, s));
     HIPCHK(hipStreamSynchronize(s));
     hipFree(dd);
     return XSD_OK;
+}
+
+// math mode 2 works on P16 planes: the hooks convert the caller's fp32 planes in and out
+struct TmpPlanes {
+    std::vector<float*> bufs;
+    ~TmpPlanes() { for (float* b : bufs) hipFree(b); }
+    float* make(long long npix) { float* b = nullptr; if (hipMalloc((void**)&b, npix * 128) != hipSuccess) return nullptr; bufs.push_back(b); return b; }
+};
+
+static hipError_t run_conv(xsd_engine* e, ConvParams& p, hipStream_t s)
+{
+    p.zero = e->zero_page;
+    if (e->math == 2) return launch_conv3x3_p16(p, s);
+    return e->big ? launch_conv3x3_big(p, e->math, s) : launch_conv3x3_mfma(p, e->math, s);
 }
 
 int xsd_test_conv3x3(xsd_engine* e, const float* const* in_planes, int n_in, const float* dev_w_oihw, const float* dev_bias,
@@ -766,12 +790,26 @@ int xsd_test_conv3x3(xsd_engine* e, const float* const* in_planes, int n_in, con
     float *fwd = nullptr, *bwd = nullptr;
     int rc = pack_single(dev_w_oihw, 32 * n_out, 32 * n_in, &fwd, &bwd, e->math, s);
     if (rc) return rc;
+    const long long npix = (long long)B * H * W;
+    TmpPlanes tmp;
+    std::vector<const float*> ins(n_in);
+    std::vector<float*> outs(n_out);
+    for (int i = 0; i < n_in; ++i) {
+        ins[i] = in_planes[i];
+        if (e->math == 2) { float* t = tmp.make(npix); if (!t) return fail(XSD_ERR_NOMEM, "tmp"); launch_plane_convert(in_planes[i], t, npix, 1, s); ins[i] = t; }
+    }
+    for (int j = 0; j < n_out; ++j) {
+        outs[j] = out_planes[j];
+        if (e->math == 2) { float* t = tmp.make(npix); if (!t) return fail(XSD_ERR_NOMEM, "tmp"); outs[j] = t; }
+    }
     Builder b(e, B, H, W, false, 0);
     ConvParams p = b.conv_base(0);
     p.n_in = n_in; p.n_out = n_out; p.wpanel = fwd; p.bias = dev_bias;
-    for (int i = 0; i < n_in; ++i) p.in[i] = b.std_in(in_planes[i], 0);
-    for (int j = 0; j < n_out; ++j) { b.std_out(p.out[j], out_planes[j], 0); p.out[j].slope = slope; }
-    hipError_t err = e->big ? launch_conv3x3_big(p, e->math, s) : launch_conv3x3_mfma(p, e->math, s);
+    for (int i = 0; i < n_in; ++i) p.in[i] = b.std_in(ins[i], 0);
+    for (int j = 0; j < n_out; ++j) { b.std_out(p.out[j], outs[j], 0); p.out[j].slope = slope; }
+    hipError_t err = run_conv(e, p, s);
+    if (err == hipSuccess && e->math == 2)
+        for (int j = 0; j < n_out; ++j) launch_plane_convert(outs[j], out_planes[j], npix, 0, s);
     hipStreamSynchronize(s);
     hipFree(fwd); hipFree(bwd);
     if (err != hipSuccess) return fail(XSD_ERR_HIP, "conv launch: %s", hipGetErrorString(err));
@@ -786,25 +824,45 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
     float *fwd = nullptr, *bwd = nullptr;
     int rc = pack_single(dev_w_oihw, 32, 32 * n_in, &fwd, &bwd, e->math, s);
     if (rc) return rc;
+    const long long npix = (long long)B * H * W;
+    TmpPlanes tmp;
+    std::vector<const float*> ins(n_in);
+    std::vector<float*> dxs(n_in);
+    const float* g = dev_g_plane;
+    if (e->math == 2) {
+        float* t = tmp.make(npix); if (!t) return fail(XSD_ERR_NOMEM, "tmp");
+        launch_plane_convert(dev_g_plane, t, npix, 1, s); g = t;
+    }
+    for (int i = 0; i < n_in; ++i) {
+        ins[i] = in_planes[i]; dxs[i] = dx_planes[i];
+        if (e->math == 2) {
+            float* t = tmp.make(npix); float* u = tmp.make(npix);
+            if (!t || !u) return fail(XSD_ERR_NOMEM, "tmp");
+            launch_plane_convert(in_planes[i], t, npix, 1, s); ins[i] = t; dxs[i] = u;
+        }
+    }
     Builder b(e, B, H, W, false, 0);
     ConvParams p = b.conv_base(0);
-    p.n_in = 1; p.n_out = n_in; p.wpanel = bwd; p.in[0] = b.std_in(dev_g_plane, 0);
-    for (int j = 0; j < n_in; ++j) b.std_out(p.out[j], dx_planes[j], 0);
-    hipError_t err = e->big ? launch_conv3x3_big(p, e->math, s) : launch_conv3x3_mfma(p, e->math, s);
+    p.n_in = 1; p.n_out = n_in; p.wpanel = bwd; p.in[0] = b.std_in(g, 0);
+    for (int j = 0; j < n_in; ++j) b.std_out(p.out[j], dxs[j], 0);
+    hipError_t err = run_conv(e, p, s);
     if (err == hipSuccess) {
         WgradParams wp; memset(&wp, 0, sizeof(wp));
         wp.B = B; wp.H = H; wp.W = W; wp.tilesX = p.tilesX; wp.tilesY = p.tilesY; wp.n_in = n_in; wp.n_g = 1; wp.nparts = e->nparts;
-        for (int i = 0; i < n_in; ++i) wp.x[i] = b.std_in(in_planes[i], 0);
-        wp.g[0] = b.std_in(dev_g_plane, 0);
-        wp.partial = e->wg_partial; wp.bias_partial = e->wg_bias_partial;
-        err = launch_wgrad_mfma(wp, e->math, s);
+        for (int i = 0; i < n_in; ++i) wp.x[i] = b.std_in(ins[i], 0);
+        wp.g[0] = b.std_in(g, 0);
+        wp.partial = e->wg_partial; wp.bias_partial = e->wg_bias_partial; wp.zero = e->zero_page;
+        err = e->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, e->math, s);
         if (err == hipSuccess) {
             WgradReduceParams rp; memset(&rp, 0, sizeof(rp));
             rp.partial = e->wg_partial; rp.bias_partial = e->wg_bias_partial; rp.nparts = e->nparts; rp.n_in = n_in; rp.n_g = 1;
             rp.cin_total = 32 * n_in; rp.cout_total = 32; rp.shuffle = 0; rp.scale = 1.f; rp.dw = dev_dw_oihw; rp.db = dev_db;
+            rp.p16 = e->math == 2;
             err = launch_wgrad_reduce(rp, s);
         }
     }
+    if (err == hipSuccess && e->math == 2)
+        for (int j = 0; j < n_in; ++j) launch_plane_convert(dxs[j], dx_planes[j], npix, 0, s);
     hipStreamSynchronize(s);
     hipFree(fwd); hipFree(bwd);
     if (err != hipSuccess) return fail(XSD_ERR_HIP, "bwd launch: %s", hipGetErrorString(err));

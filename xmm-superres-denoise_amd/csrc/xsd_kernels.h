@@ -54,6 +54,7 @@ struct ConvParams {
     const float* bias;   // [n_out*32] or nullptr
     int ablate;          // diagnostic ablation bits (0 in production): 1 skip input loads, 2 skip weight loads, 4 skip stores, 8 skip MFMA loop
     int pad_;
+    const void* zero;    // >= 64 B of zeros in HBM (math mode 2: DMA source for zero padding)
     unsigned long long* dbg; // diagnostic phase stamps (null in production): [grid][8] accumulated shader cycles
     OutDesc out[5];
 };
@@ -68,6 +69,7 @@ struct WgradParams {
     PlaneIn g[4];
     float* partial;      // [nparts][n_g][n_in][9][32 ci][32 co]
     float* bias_partial; // [nparts][n_g][32]
+    const void* zero;    // zero page (P16 kernel)
 };
 
 struct WgradReduceParams {
@@ -76,6 +78,7 @@ struct WgradReduceParams {
     int nparts, n_in, n_g;
     int cin_total, cout_total;
     int shuffle;   // 1: output channel oc = 4*co + n (pixel-shuffle conv), else oc = 32*n + co
+    int p16;       // 1: partial rows/cols are P16 positions (p16.h), map back to channels
     float scale;
     float* dw;     // OIHW [cout_total][cin_total][3][3]
     float* db;     // [cout_total]
@@ -100,6 +103,7 @@ struct EdgeExpandParams { // 1 -> 32 conv:  out[p][c] = bias[c] + sum_tap s[p+ta
     float* out;          // [B][H][W][32]
     const float* mask;   // plane or null
     float mslope;
+    int p16;             // planes (out, mask) are P16
 };
 struct EdgeReduceParams { // 32 -> 1 conv: pre[p] = bias + sum_tap sum_c f[p+tap][c] * w[tap][c] (+ skip[p]); y = clamp(pre)
     int B, H, W;
@@ -111,6 +115,7 @@ struct EdgeReduceParams { // 32 -> 1 conv: pre[p] = bias + sum_tap sum_c f[p+tap
     float* y;            // output
     int clamp01;
     const float* addto;  // y = value + addto[p] (used for dx = dgrad + skip-grad), may be null
+    int p16;             // plane f is P16
 };
 struct EdgeWgradParams { // out[tap][c] = sum_p f[p][c] * s[p+tap]; bsum[c] = sum_p f[p][c]; ssum = sum_p s[p]
     int B, H, W;
@@ -118,6 +123,7 @@ struct EdgeWgradParams { // out[tap][c] = sum_p f[p][c] * s[p+tap]; bsum[c] = su
     const float* s;
     float* partial;      // [nblocks][9*32 + 32 + 1]
     int nblocks;
+    int p16;             // plane f is P16
 };
 
 } // namespace xsd

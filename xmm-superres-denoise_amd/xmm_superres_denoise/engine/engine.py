@@ -49,14 +49,15 @@ class Engine:
         except Exception:
             pass
 
-    MATH = {"fp32": 0, "bf16x3": 1}
+    MATH = {"fp32": 0, "bf16x3": 1, "bf16x3_p16": 2}
 
     def set_math(self, mode: str):
-        """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA, fp32 accumulate); include/xsd.h: xsd_set_math."""
+        """'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16 MFMA over fp32 planes) or 'bf16x3_p16' (split-bf16 MFMA over
+        pre-split P16 planes, LDS-DMA staging); include/xsd.h: xsd_set_math."""
         check(self.L.xsd_set_math(self.h, self.MATH[mode]))
 
     def get_math(self) -> str:
-        return {0: "fp32", 1: "bf16x3"}[int(self.L.xsd_get_math(self.h))]
+        return {0: "fp32", 1: "bf16x3", 2: "bf16x3_p16"}[int(self.L.xsd_get_math(self.h))]
 
     # ---- weights
     def pack(self, flat_params: torch.Tensor):

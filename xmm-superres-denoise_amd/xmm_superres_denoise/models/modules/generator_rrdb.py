@@ -106,7 +106,7 @@ class _GeneratorRRDB(nn.Module):
 
     def set_math(self, mode: str):
         """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA with fp32 accumulation, ~5e-6 whole-net error)."""
-        if mode not in ("fp32", "bf16x3"):
+        if mode not in ("fp32", "bf16x3", "bf16x3_p16"):
             raise ValueError(mode)
         self._math = mode
         if self._engine is not None:
