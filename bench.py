@@ -81,6 +81,23 @@ def cpu_baseline(kind: str, train: bool):
                       f"restatement of the reference graph (oracle/oracle.py:torch_forward), {dt:.1f} s"}
 
 
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md); bf16x3 spends 3 MFMAs per fp32 product
+HBM_PEAK_GBPS = 8000.0
+
+
+def pmc_traffic(math: str, batch: int, klass: str):
+    """HBM bytes per launch from the committed PMC passes (tools/traffic.sh -> profiles/r01_traffic_<math>.json),
+    valid only for the workload/batch they were collected on; None otherwise."""
+    f = os.path.join(ROOT, "profiles", f"r01_traffic_{math}.json")
+    try:
+        d = json.load(open(f))
+        if d.get("per_gpu_batch") == batch and d.get("workload") == "dn_train":
+            return d[klass]["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,10 +105,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="dn_train", choices=["dn_train", "sr_train", "dn_fwd", "sr_fwd"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 32 at N=1, 16 at N>1; sr_fwd: 16)")
-    ap.add_argument("--math", default=os.environ.get("XSD_MATH", "fp32"), choices=["fp32", "bf16x3", "bf16x3_p16"],
+    ap.add_argument("--math", default=os.environ.get("XSD_MATH", "bf16x3_p16"), choices=["fp32", "bf16x3", "bf16x3_p16"],
                     help="MFMA math mode of the conv kernels (include/xsd.h: xsd_set_math)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-exact", action="store_true", help="skip the short exact-fp32 comparison run")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,11 +118,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus} (one process per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    # one process per GPU; XSD_DIST_BACKEND=gloo lets the multi-process path be rehearsed on a single-GPU box
+    backend = os.environ.get("XSD_DIST_BACKEND", "nccl")
+    dev_index = local_rank % ndev if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from xmm_superres_denoise.models import GeneratorRRDB_DN, GeneratorRRDB_SR
     from xmm_superres_denoise.parallel import DataParallelTrainer
@@ -134,37 +161,57 @@ def main():
         with torch.no_grad():
             return model(x)
 
-    for _ in range(args.warmup):
-        step()
-    if not args.no_profile:
-        eng.profile_enable(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed(nwarm, nsteps, profile):
+        for _ in range(nwarm):
+            step()
+        if profile:
+            eng.profile_enable(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        prof = None
+        if profile:
+            prof = {0: eng.profile_read(0), 1: eng.profile_read(1)}
+            eng.profile_enable(False)
+        return dt, prof
 
-    prof = None
-    if not args.no_profile:
-        prof = {0: eng.profile_read(0), 1: eng.profile_read(1)}
-        eng.profile_enable(False)
+    dt, prof = timed(args.warmup, args.steps, not args.no_profile)
+
+    # ---- exact-fp32 companion measurement (same process, same inputs): throughput of math mode "fp32" and the largest
+    # output difference between the two modes on one forward pass
+    exact = None
+    if args.math != "fp32" and not args.no_exact:
+        with torch.no_grad():
+            y_fast = model(x[:2]).clone()
+        model.set_math("fp32")
+        with torch.no_grad():
+            y_ref = model(x[:2])
+        err = float((y_fast - y_ref).abs().max())
+        dte, _ = timed(1, 2, False)
+        exact = {"math": "fp32", "value": B * world * 2 / dte, "unit": "tiles/s", "ms_per_step": 1e3 * dte / 2,
+                 "max_abs_output_diff_vs_" + args.math: err, "tolerance": 1e-3}
+        model.set_math(args.math)
 
     if rank == 0:
         tiles = B * world * args.steps
+        dtype = {"fp32": "f32", "bf16x3": "bf16x3 (hi+lo split MFMA, f32 accumulate, f32 planes)",
+                 "bf16x3_p16": "bf16x3 (hi+lo split MFMA, f32 accumulate, hi|lo bf16 planes)"}[args.math]
         out = {
             "metric": "XMM 512x512 tiles/sec (train step)" if train else "XMM 512x512 tiles/sec (forward)",
             "value": tiles / dt, "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": {"dn_train": "XMM-DeNoise train step (L1 + Adam), fwd+bwd HIP kernels",
                                     "sr_train": "XMM-SuperRes 2x train step (L1 + Adam)",
                                     "dn_fwd": "XMM-DeNoise forward", "sr_fwd": "XMM-SuperRes 2x generator forward"}[args.workload],
@@ -173,16 +220,35 @@ def main():
         }
         if prof is not None and prof[0]["launches"] > 0:
             k = prof[0]
-            ach = k["flop"] / (k["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "launches": k["launches"], "avg_launch_ms": k["ms"] / k["launches"],
-                               "algorithmic_GBps": k["bytes"] / (k["ms"] * 1e-3) / 1e9}
+            sec = k["ms"] * 1e-3
+            tf = k["flop"] / sec / 1e12
+            gbs = k["bytes"] / sec / 1e9
+            kname = {"fp32": "conv3x3_mfma_kernel", "bf16x3": "conv3x3_mfma_kernel<*,SPLIT>", "bf16x3_p16": "conv3x3_p16_kernel"}[args.math]
+            traffic = pmc_traffic(args.math, B, "conv") if (train and kind == "dn" and world == 1) else None
+            if args.math == "fp32":
+                # exact fp32 MFMA: compute-bound by 4-5x
+                roof = {"bound": "mfma", "kernel": kname, "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic}
+            else:
+                # bf16x3: algorithmic intensity (~100 FLOP/B) sits at the ridge (2500/3 TFLOP/s over 8 TB/s = 104 FLOP/B);
+                # ablation shows the memory side is the longer pole, so the binding roofline reported is HBM
+                eff_peak = BF16_MFMA_PEAK_TFLOPS / 3.0
+                roof = {"bound": "hbm", "kernel": kname, "achieved": gbs, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": gbs / HBM_PEAK_GBPS, "traffic": traffic,
+                        "mfma": {"achieved": tf, "peak": eff_peak, "unit": "TFLOP/s (algorithmic fp32 FLOP; 3 bf16 MFMAs each)",
+                                 "frac": tf / eff_peak}}
+            roof.update({"launches": k["launches"], "avg_launch_ms": k["ms"] / k["launches"],
+                         "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
+                         "algorithmic_flop_per_launch": k["flop"] / k["launches"]})
             if prof[1]["launches"] > 0:
                 w = prof[1]
-                out["roofline"]["wgrad_mfma_kernel"] = {"achieved": w["flop"] / (w["ms"] * 1e-3) / 1e12,
-                                                        "frac": w["flop"] / (w["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                                                        "launches": w["launches"], "avg_launch_ms": w["ms"] / w["launches"]}
+                wsec = w["ms"] * 1e-3
+                roof["wgrad_kernel"] = {"achieved_TFLOPs": w["flop"] / wsec / 1e12, "achieved_GBps": w["bytes"] / wsec / 1e9,
+                                        "launches": w["launches"], "avg_launch_ms": w["ms"] / w["launches"],
+                                        "traffic": pmc_traffic(args.math, B, "wgrad") if (train and kind == "dn" and world == 1) else None}
+            out["roofline"] = roof
+        if exact is not None:
+            out["exact_fp32"] = exact
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, train)
         print(json.dumps(out), flush=True)

@@ -9,6 +9,7 @@
 // of the conv that produces its operand.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -72,6 +73,7 @@ struct xsd_engine {
     float* pk_bwd = nullptr;
     unsigned short* pk_fwd_s = nullptr; // bf16x3 (hi|lo) panels, same byte size / offsets as pk_fwd / pk_bwd
     unsigned short* pk_bwd_s = nullptr;
+    int chunk = 0;             // images per dense-block sweep (0 = whole batch): keeps one block's planes in the 256 MB Infinity Cache
     int ablate = 0;            // diagnostic (env XSD_ABLATE)
     int big = 0;               // conv structure: 0 = 8x32 tile, 2 WG/CU; 1 = 16x32 tile, 1 WG/CU, LDS-DMA weight ring
     int math = 0;              // 0 = exact fp32 MFMA, 1 = bf16x3 split MFMA (conv forward + input-gradient)
@@ -213,6 +215,22 @@ struct Builder {
         o.p = const_cast<float*>(r.p); o.ps = r.ps; o.rs = r.rs; o.bs = r.bs;
     }
 
+    // the same conv restricted to images [b0, b0 + nb)
+    static ConvParams slice(const ConvParams& q, int b0, int nb)
+    {
+        ConvParams p = q;
+        p.B = nb;
+        for (int i = 0; i < 5; ++i) if (p.in[i].p) p.in[i].p += (long long)b0 * p.in[i].bs;
+        for (int j = 0; j < 5; ++j) {
+            OutDesc& o = p.out[j];
+            if (o.p) o.p += (long long)b0 * o.bs;
+            if (o.e1) o.e1 += (long long)b0 * p.std_bs;
+            if (o.e2) o.e2 += (long long)b0 * p.std_bs;
+            if (o.e3) o.e3 += (long long)b0 * p.std_bs;
+            if (o.mask) o.mask += (long long)b0 * p.std_bs;
+        }
+        return p;
+    }
     Launch conv_launch(const ConvParams& p_in, bool bias_from_params, long long bias_off)
     {
         ConvParams p = p_in;
@@ -288,6 +306,7 @@ struct Builder {
             for (int r = 0; r < 3; ++r) {
                 RdbAct& a = acts[i * 3 + r];
                 a.xin = cur;
+                ConvParams rp[5];
                 for (int c = 0; c < 5; ++c) {
                     const ConvW& cw = e->rdb[(i * 3 + r) * 5 + c];
                     ConvParams p = conv_base(0);
@@ -303,8 +322,14 @@ struct Builder {
                         if (r == 2) { p.out[0].a2 = 0.2f; p.out[0].e2 = rin[i]; p.out[0].s2 = 1.f; } // out*0.2 + x (:70)
                         a.out = o;
                     }
-                    F.push_back(conv_launch(p, true, cw.b_off));
+                    rp[c] = p;
                 }
+                // Sweep the dense block in batch chunks: with <= 1-2 images per sweep the block's six planes
+                // (6 x 33.5 MB per 512^2 image) stay in the Infinity Cache between conv_k and conv_{k+1..5}.
+                const int cb = (e->chunk > 0 && e->chunk < B) ? e->chunk : B;
+                for (int b0 = 0; b0 < B; b0 += cb)
+                    for (int c = 0; c < 5; ++c)
+                        F.push_back(conv_launch(slice(rp[c], b0, std::min(cb, B - b0)), true, e->rdb[(i * 3 + r) * 5 + c].b_off));
                 for (int k = 0; k < 4; ++k) release(a.xs[k], 0);
                 if (r > 0) release(a.xin, 0);
                 cur = a.out;
@@ -518,6 +543,7 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     xsd_engine* e = new xsd_engine();
     e->cfg = *cfg;
     if (const char* m = getenv("XSD_ABLATE")) e->ablate = atoi(m);
+    if (const char* m = getenv("XSD_CHUNK")) e->chunk = atoi(m);
     if (const char* m = getenv("XSD_CONV")) e->big = strcmp(m, "big") == 0 ? 1 : 0;
     if (const char* m = getenv("XSD_MATH")) e->math = (strcmp(m, "bf16x3_p16") == 0 || strcmp(m, "2") == 0) ? 2 : (strcmp(m, "bf16x3") == 0 || strcmp(m, "1") == 0) ? 1 : 0;
     const int blocks = cfg->num_res_blocks, nup = cfg->kind == XSD_KIND_SR ? cfg->num_upsample : 0;
