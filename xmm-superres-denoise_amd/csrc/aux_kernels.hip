@@ -265,7 +265,7 @@ __global__ void pack_weights_kernel(const float* params, const PackDesc* descs, 
         { // dgrad: panel = s*nn + n
             const int s = panel / nn, n = panel % nn;
             const int oc = d.shuffle ? (4 * k + n) : (32 * n + k);
-            bwd[d.dst_bwd + e] = W[((long long)oc * d.cin + 32 * s + c) * 9 + (8 - tap)];
+            bwd[d.dst_bwd + e] = d.bwd_scale * W[((long long)oc * d.cin + 32 * s + c) * 9 + (8 - tap)];
         }
     }
 }
@@ -298,7 +298,7 @@ __global__ void pack_weights_split_kernel(const float* params, const PackDesc* d
         {
             const int s = panel / nn, n = panel % nn;
             const int oc = d.shuffle ? (4 * k + n) : (32 * n + k);
-            wb = W[((long long)oc * d.cin + 32 * s + c) * 9 + (8 - tap)];
+            wb = d.bwd_scale * W[((long long)oc * d.cin + 32 * s + c) * 9 + (8 - tap)];
         }
         const __bf16 fh = (__bf16)wf, bh = (__bf16)wb;
         const __bf16 fl = (__bf16)(wf - (float)fh), bl = (__bf16)(wb - (float)bh);
@@ -335,7 +335,7 @@ __global__ void pack_weights_p16_kernel(const float* params, const PackDesc* des
         {
             const int s = panel / nn, n = panel % nn;
             const int oc = d.shuffle ? (4 * kch + n) : (32 * n + kch);
-            wb = W[((long long)oc * d.cin + 32 * s + m) * 9 + (8 - tap)];
+            wb = d.bwd_scale * W[((long long)oc * d.cin + 32 * s + m) * 9 + (8 - tap)];
         }
         const __bf16 fh = (__bf16)wf, bh = (__bf16)wb;
         const __bf16 fl = (__bf16)(wf - (float)fh), bl = (__bf16)(wb - (float)bh);

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(BT, 2) void conv3x3_big_kernel(const ConvParams P)
     };
     // ---- weight panel by LDS-DMA: 36 chunks of 1 KiB, wave w moves chunks w, w+8, ...
     auto dma_w = [&](int s, int buf) {
-        const char* src = reinterpret_cast<const char*>(P.wpanel + (long long)s * PANEL_FLOATS) + lane * 16;
+        const char* src = reinterpret_cast<const char*>(P.wstep[s]) + lane * 16;
         char* dst = w_lds + buf * W_LDS_BYTES;
 #pragma unroll
         for (int c0 = 0; c0 < 40; c0 += BW) {

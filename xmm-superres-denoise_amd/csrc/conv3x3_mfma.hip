@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
         }
     };
     auto load_w = [&](int s) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(P.wpanel + (long long)s * PANEL_FLOATS);
+        const f32x4* src = reinterpret_cast<const f32x4*>(P.wstep[s]);
         if (P.ablate & 2) return;
 #pragma unroll
         for (int r = 0; r < W_ROUNDS; ++r) pw[r] = src[r * 256 + tid];

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(QT, 2) void conv3x3_p16_kernel(const ConvParams P)
         }
     };
     auto dma_w = [&](int s, int s2, int buf) {
-        const char* src = reinterpret_cast<const char*>(P.wpanel) + ((long long)s * 2 + s2) * QW_BYTES + lane * 16;
+        const char* src = reinterpret_cast<const char*>(P.wstep[s]) + s2 * QW_BYTES + lane * 16;
         char* dst = smem + (buf ? Q_W1 : Q_W0);
         if (P.ablate & 2) return;
 #pragma unroll

@@ -53,6 +53,7 @@ struct ConvW {       // one MFMA conv's weights
     int cout, cin, shuffle;
     long long fwd_off, bwd_off; // packed offsets (floats)
     long long sbias_off;        // shuffled-bias offset (shuffle convs) or -1
+    float bwd_scale = 1.f;      // folded into the input-gradient panels
 };
 
 typedef std::function<hipError_t(hipStream_t)> Launch;
@@ -234,6 +235,10 @@ struct Builder {
     Launch conv_launch(const ConvParams& p_in, bool bias_from_params, long long bias_off)
     {
         ConvParams p = p_in;
+        {
+            const int nst = p.n_out > 1 ? p.n_out : p.n_in;
+            for (int i = 0; i < nst; ++i) if (!p.wstep[i]) p.wstep[i] = p.wpanel + (long long)i * PANEL_FLOATS;
+        }
         xsd_engine* eng = e;
         const double px = (double)p.B * p.H * p.W;
         const double flop = 2.0 * 9 * 32 * 32 * p.n_in * p.n_out * px;
@@ -456,25 +461,31 @@ struct Builder {
                 const ConvW* cw = &e->rdb[(i * 3 + r) * 5];
                 dS[0] = alloc(0);
                 const float* xpl[5] = {a.xin, a.xs[0], a.xs[1], a.xs[2], a.xs[3]};
-                for (int c = 4; c >= 0; --c) {
-                    const float* G = c == 4 ? dOut : dS[c + 1];
+                // Input-gradients as K-loops (no read-modify-write): dS_j = sum_{c>j} conv^T_c[j](G_c) in ONE launch over
+                // the planes G_5 = dOut, G_4..G_{j+1}; its epilogue adds the residual-path terms (j = 0) or applies
+                // lrelu'(x_j) (j >= 1), which makes dS_j the G_j of conv_j.  conv5's 0.2 / 0.04 factor lives in its
+                // transposed panels (PackDesc.bwd_scale); its weight gradient uses the unscaled dOut and scales in the reduce.
+                const float* Gp[6] = {nullptr, dS[1], dS[2], dS[3], dS[4], dOut}; // G_c, c = 1..5
+                for (int c = 4; c >= 0; --c) { // conv index c (0-based) = conv_{c+1}
                     std::vector<PlaneIn> xs;
-                    for (int k = 0; k <= c; ++k) xs.push_back(std_in(xpl[k], 0));
-                    wgrad_launch(S, 0, xs, {std_in(G, 0)}, cw[c], c == 4 ? gscale : 1.f);
+                    for (int kk = 0; kk <= c; ++kk) xs.push_back(std_in(xpl[kk], 0));
+                    wgrad_launch(S, 0, xs, {std_in(Gp[c + 1], 0)}, cw[c], c == 4 ? gscale : 1.f);
+                    // now every G needed by dS_c exists: G_5 .. G_{c+1}
+                    const int j = c;
                     ConvParams p = conv_base(0);
-                    p.n_in = 1; p.n_out = c + 1; p.in[0] = std_in(G, 0); p.wpanel = bwdp(cw[c].bwd_off);
-                    for (int j = 0; j <= c; ++j) {
-                        OutDesc& o = p.out[j];
-                        std_out(o, dS[j], 0);
-                        if (c == 4) {
-                            o.a1 = gscale;
-                            if (j == 0) {
-                                o.e1 = dOut; o.s1 = r == 2 ? 0.2f : 1.f;
-                                if (r == 0) { o.e2 = dR; o.s2 = 1.f; if (i == 0) { o.e3 = dT; o.s3 = 1.f; } }
-                            }
-                        } else o.accumulate = 1;
-                        if (j == c && j >= 1) { o.mask = xpl[j]; o.mslope = 0.2f; } // last contribution to d(x_j): apply lrelu'
+                    p.n_in = 5 - j; p.n_out = 1;
+                    for (int i = 0; i < 5 - j; ++i) { // step i reads G_{5-i}
+                        const int cc = 5 - i;          // 1-based conv whose gradient plane this is
+                        p.in[i] = std_in(Gp[cc], 0);
+                        p.wstep[i] = bwdp(cw[cc - 1].bwd_off) + (long long)j * PANEL_FLOATS;
                     }
+                    p.wpanel = p.wstep[0];
+                    OutDesc& o = p.out[0];
+                    std_out(o, dS[j], 0);
+                    if (j == 0) {
+                        o.e1 = dOut; o.s1 = r == 2 ? 0.2f : 1.f;
+                        if (r == 0) { o.e2 = dR; o.s2 = 1.f; if (i == 0) { o.e3 = dT; o.s3 = 1.f; } }
+                    } else { o.mask = xpl[j]; o.mslope = 0.2f; }
                     S.push_back(conv_launch(p, false, 0));
                 }
                 if (dOut != dR) release(dOut, 0, true);
@@ -560,7 +571,11 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     for (int i = 0; i < blocks; ++i) {
         e->rrdb_begin.push_back(off);
         for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 5; ++c) e->rdb.push_back(mk(32, 32 * (c + 1), 0));
+            for (int c = 0; c < 5; ++c) {
+                e->rdb.push_back(mk(32, 32 * (c + 1), 0));
+                // conv5's gradient arrives as 0.2*dOut (x5*0.2 + x) and, for RDB3, 0.2*0.2*dOut (out*0.2 + x): fold it
+                if (c == 4) e->rdb.back().bwd_scale = r == 2 ? 0.04f : 0.2f;
+            }
     }
     e->rrdb_begin.push_back(off);
     e->trunk = mk(32, 32, 0);
@@ -571,7 +586,7 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     e->pk_floats = pk;
 
     std::vector<PackDesc> descs;
-    auto add = [&](const ConvW& c) { PackDesc d; d.src_w = c.w_off; d.dst_fwd = c.fwd_off; d.dst_bwd = c.bwd_off; d.cout = c.cout; d.cin = c.cin; d.shuffle = c.shuffle; d.pad = 0; descs.push_back(d); };
+    auto add = [&](const ConvW& c) { PackDesc d; d.src_w = c.w_off; d.dst_fwd = c.fwd_off; d.dst_bwd = c.bwd_off; d.cout = c.cout; d.cin = c.cin; d.shuffle = c.shuffle; d.bwd_scale = c.bwd_scale; descs.push_back(d); };
     for (auto& c : e->rdb) add(c);
     add(e->trunk);
     for (auto& c : e->up) add(c);
@@ -780,7 +795,7 @@ int xsd_profile_read(xsd_engine* e, int klass, double* total_ms, int64_t* launch
 static int pack_single(const float* dev_w, int cout, int cin, float** fwd, float** bwd, int math, hipStream_t s)
 {
     const long long n = (long long)(cout / 32) * (cin / 32) * PANEL_FLOATS;
-    PackDesc d; d.src_w = 0; d.dst_fwd = 0; d.dst_bwd = 0; d.cout = cout; d.cin = cin; d.shuffle = 0; d.pad = 0;
+    PackDesc d; d.src_w = 0; d.dst_fwd = 0; d.dst_bwd = 0; d.cout = cout; d.cin = cin; d.shuffle = 0; d.bwd_scale = 1.f;
     PackDesc* dd = nullptr;
     HIPCHK(hipMalloc((void**)fwd, sizeof(float) * n));
     HIPCHK(hipMalloc((void**)bwd, sizeof(float) * n));
@@ -804,6 +819,7 @@ struct TmpPlanes {
 static hipError_t run_conv(xsd_engine* e, ConvParams& p, hipStream_t s)
 {
     p.zero = e->zero_page;
+    for (int i = 0; i < (p.n_out > 1 ? p.n_out : p.n_in); ++i) p.wstep[i] = p.wpanel + (long long)i * PANEL_FLOATS;
     if (e->math == 2) return launch_conv3x3_p16(p, s);
     return e->big ? launch_conv3x3_big(p, e->math, s) : launch_conv3x3_mfma(p, e->math, s);
 }

@@ -50,7 +50,8 @@ struct ConvParams {
     int std_rs;          // W*32
     long long std_bs;    // H*W*32
     PlaneIn in[5];
-    const float* wpanel; // [n_out][n_in] panels (one of the two is 1), PANEL_FLOATS each
+    const float* wpanel; // [n_out][n_in] panels (one of the two is 1), PANEL_FLOATS each (host side; kernels read wstep)
+    const float* wstep[5]; // weight panel of each step (K-loop step or output chunk)
     const float* bias;   // [n_out*32] or nullptr
     int ablate;          // diagnostic ablation bits (0 in production): 1 skip input loads, 2 skip weight loads, 4 skip stores, 8 skip MFMA loop
     int pad_;
@@ -91,7 +92,7 @@ struct PackDesc {
     long long dst_bwd;   // offset into packed dgrad buffer
     int cout, cin;       // multiples of 32
     int shuffle;
-    int pad;
+    float bwd_scale;     // folded into the transposed (input-gradient) panels: 0.2 / 0.04 for conv5 (rrdb_blocks.py:54,70)
 };
 
 // edge layers (Cin=1 or Cout=1): HBM-bound VALU kernels
