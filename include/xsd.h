@@ -106,6 +106,14 @@ int xsd_adam_step(xsd_engine* e, float* dev_params, const float* dev_grads, floa
  * stretch: 0 linear, 1 sqrt, 2 asinh, 3 log.  do_normalize = 0 returns the masked, padded counts (bit-exact). */
 int xsd_mask_pad_normalize(const void* dev_counts, int counts_is_int32, const uint8_t* dev_mask_or_null, float* dev_out,
                            int B, int Hin, int Win, int res, int do_normalize, float max_val, int stretch, void* stream);
+/* Whole sample composition of XmmDataset (data/dataset.py:24-49 + :267-268) in one kernel, straight from FITS payload
+ * words: img (+ agn) (+ background) summed in fp32 like load_fits' float images, * detector mask, optional nearest
+ * upsample x s with / s^2 (ImageUpsample, dataset.py:44-45), centred pad / crop to res, optional normalize.
+ * is_int32: BITPIX 32 counts (else IEEE float32); big_endian != 0: words are in FITS byte order (byte-swapped on load),
+ * so a primary HDU's data block can be copied to the device unmodified.  Bit-exact when do_normalize = 0. */
+int xsd_compose_input(const void* dev_img, const void* dev_agn_or_null, const void* dev_bkg_or_null, int is_int32, int big_endian,
+                      const uint8_t* dev_mask_or_null, float* dev_out, int B, int Hin, int Win, int upsample, int res,
+                      int do_normalize, float max_val, int stretch, void* stream);
 /* Normalize.normalize_image (inverse = 0) / denormalize_image (inverse = 1), max_val > 0 (transforms/normalize.py:66-92) */
 int xsd_normalize(const float* dev_in, float* dev_out, int64_t n, float max_val, int stretch, int inverse, void* stream);
 /* ImageUpsample: nearest x scale then / scale^2 (transforms/imageupsample.py:10-26); in [N][H][W] */

@@ -63,3 +63,24 @@ def test_detector_mask_pad_bit_exact_full_size():
     assert out_i[:, 0, :2].sum() == 0 and out_i[:, 0, -3:].sum() == 0
     fused = load_and_prepare(torch.from_numpy(counts).cuda(), md, 416, 0.0022336, "sqrt").cpu().numpy()
     assert np.abs(fused - np.stack([oracle.normalize(r, 0.0022336, "sqrt") for r in ref])).max() <= 1.2e-7
+
+
+def test_compose_input_from_raw_fits_words_bit_exact():
+    """XmmDataset sample composition in one kernel: (img + agn + bkg) * mask -> pad, from big-endian FITS words, and
+    the real-data path img * mask -> nearest x2 / 4 -> pad 832 (data/dataset.py:24-49); bit-exact vs the numpy oracle."""
+    from xmm_superres_denoise.engine import compose_input
+    z = np.load(os.path.join(G, "example_data.npz"))
+    m1 = np.unpackbits(z["mask1x_bits"])[: int(np.prod(z["mask1x_shape"]))].reshape(z["mask1x_shape"])
+    a, b, c = z["sr_counts_lr_0"], z["sr_counts_lr_1"], z["dn_counts20_0"]
+    ref = oracle.mask_pad((a.astype(np.float32) + b.astype(np.float32) + c.astype(np.float32)), m1, 416)
+    md = torch.from_numpy(m1).cuda()
+    be = [torch.from_numpy(v.astype(">i4").view(np.int32).copy())[None].cuda() for v in (a, b, c)]  # raw FITS byte order
+    out = compose_input(be[0], be[1], be[2], md, 416, None, big_endian=True).cpu().numpy()
+    assert np.array_equal(out[0], ref)
+    ne = [torch.from_numpy(v.astype(np.int32))[None].cuda() for v in (a, b, c)]
+    assert np.array_equal(compose_input(ne[0], ne[1], ne[2], md, 416, None).cpu().numpy()[0], ref)
+    # real-data HR path: mask, nearest x2 with /4, pad to 832
+    masked = c.astype(np.float32) * m1.astype(np.float32)
+    ref_up = oracle.reshape_img_to_res(oracle.image_upsample(masked[None], 2), 832)
+    got = compose_input(ne[2], None, None, md, 832, None, upsample=2).cpu().numpy()[0]
+    assert np.array_equal(got, ref_up)

@@ -409,20 +409,33 @@ __device__ __forceinline__ float stretch_inv(float v, int mode)
 // counts (int32 or float32) [B][Hin][Win] (* mask uint8 [Hin][Win]) -> centred zero pad/crop -> [B][res][res]
 // -> optional Normalize.  Mask multiply by exactly 0/1 is a select, so the masked/padded image is bit-exact
 // (data/dataset.py:41-47, data/tools.py:103-126, transforms/normalize.py:66-82).
+__device__ __forceinline__ float mpn_load(const MaskPadParams& P, const void* img, long long idx)
+{
+    unsigned int w = reinterpret_cast<const unsigned int*>(img)[idx];
+    if (P.big_endian) w = __builtin_bswap32(w);
+    return P.counts_i32 ? (float)(int)w : __builtin_bit_cast(float, w);
+}
 __global__ void mask_pad_normalize_kernel(MaskPadParams P)
 {
+    const int s = P.upsample > 1 ? P.upsample : 1;
+    const int Hs = P.Hin * s, Ws = P.Win * s; // size after the optional nearest upsample
     const long long total = (long long)P.B * P.res * P.res;
+    const void* img0 = P.counts_i32 ? (const void*)P.counts_i32 : (const void*)P.counts_f32;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int ox = (int)(i % P.res);
         const long long r = i / P.res;
         const int oy = (int)(r % P.res);
         const int b = (int)(r / P.res);
-        const int iy = oy - P.y_top, ix = ox - P.x_left;
+        const int uy = oy - P.y_top, ux = ox - P.x_left;
         float v = 0.f;
-        if (iy >= 0 && iy < P.Hin && ix >= 0 && ix < P.Win) {
+        if (uy >= 0 && uy < Hs && ux >= 0 && ux < Ws) {
+            const int iy = uy / s, ix = ux / s;
             const long long src = ((long long)b * P.Hin + iy) * P.Win + ix;
-            v = P.counts_i32 ? (float)P.counts_i32[src] : P.counts_f32[src];
+            v = mpn_load(P, img0, src);
+            if (P.extra1) v += mpn_load(P, P.extra1, src);
+            if (P.extra2) v += mpn_load(P, P.extra2, src);
             if (P.mask) v = v * (float)P.mask[(long long)iy * P.Win + ix];
+            if (s > 1) v = v / (float)(s * s);
         }
         if (P.do_norm) {
             v = fminf(fmaxf(v, 0.f), P.max_val) / P.max_val;

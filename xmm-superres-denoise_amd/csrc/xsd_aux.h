@@ -13,6 +13,12 @@ struct MaskPadParams {
     int y_top, x_left;         // floor((res-Hin)/2), floor((res-Win)/2)  (data/tools.py:111-116); negative = crop
     int do_norm, mode;         // mode: 0 linear, 1 sqrt, 2 asinh, 3 log
     float max_val;
+    // optional extra count images summed before the mask (img += agn; img += background, data/dataset.py:33-39);
+    // same dtype/shape/endianness as the main image
+    const void* extra1;
+    const void* extra2;
+    int big_endian;            // int32/float32 words are FITS big-endian: byte-swap on load
+    int upsample;              // nearest x s then / s^2 before the pad (ImageUpsample, dataset.py:44-45); 1 = none
 };
 
 hipError_t launch_conv3x3_mfma(const ConvParams& p, int split, hipStream_t stream);

@@ -730,6 +730,23 @@ int xsd_mask_pad_normalize(const void* dev_counts, int counts_is_int32, const ui
     if (counts_is_int32) p.counts_i32 = (const int32_t*)dev_counts; else p.counts_f32 = (const float*)dev_counts;
     p.mask = dev_mask_or_null; p.out = dev_out; p.B = B; p.Hin = Hin; p.Win = Win; p.res = res;
     p.y_top = (int)std::floor((res - Hin) / 2.0); p.x_left = (int)std::floor((res - Win) / 2.0);
+    p.do_norm = do_normalize; p.mode = stretch; p.max_val = max_val; p.upsample = 1;
+    HIPCHK(launch_mask_pad_normalize(p, (hipStream_t)stream));
+    return XSD_OK;
+}
+
+int xsd_compose_input(const void* dev_img, const void* dev_agn_or_null, const void* dev_bkg_or_null, int is_int32, int big_endian,
+                      const uint8_t* dev_mask_or_null, float* dev_out, int B, int Hin, int Win, int upsample, int res,
+                      int do_normalize, float max_val, int stretch, void* stream)
+{
+    if (!dev_img || !dev_out || B < 1 || Hin < 1 || Win < 1 || res < 1 || upsample < 1) return fail(XSD_ERR_ARG, "bad argument");
+    if (stretch < 0 || stretch > 3) return fail(XSD_ERR_ARG, "stretch must be 0..3");
+    if (do_normalize && !(max_val > 0.f)) return fail(XSD_ERR_ARG, "max_val must be > 0 on the fused path");
+    MaskPadParams p; memset(&p, 0, sizeof(p));
+    if (is_int32) p.counts_i32 = (const int32_t*)dev_img; else p.counts_f32 = (const float*)dev_img;
+    p.extra1 = dev_agn_or_null; p.extra2 = dev_bkg_or_null; p.big_endian = big_endian; p.upsample = upsample;
+    p.mask = dev_mask_or_null; p.out = dev_out; p.B = B; p.Hin = Hin; p.Win = Win; p.res = res;
+    p.y_top = (int)std::floor((res - Hin * upsample) / 2.0); p.x_left = (int)std::floor((res - Win * upsample) / 2.0);
     p.do_norm = do_normalize; p.mode = stretch; p.max_val = max_val;
     HIPCHK(launch_mask_pad_normalize(p, (hipStream_t)stream));
     return XSD_OK;

@@ -144,6 +144,31 @@ def mask_pad_normalize(counts: torch.Tensor, mask: torch.Tensor | None, res: int
     return out
 
 
+def compose_input(img: torch.Tensor, agn: torch.Tensor | None, bkg: torch.Tensor | None, mask: torch.Tensor | None,
+                  res: int, max_val: float | None, stretch: str = "linear", upsample: int = 1,
+                  big_endian: bool = False) -> torch.Tensor:
+    """One-kernel sample composition (include/xsd.h: xsd_compose_input): img (+agn) (+bkg) -> * mask -> optional nearest
+    upsample / s^2 -> centred pad to res -> optional normalize.  img/agn/bkg: [B,Hin,Win] int32 or float32 (CUDA); with
+    big_endian=True they hold raw FITS words (e.g. torch.frombuffer of the HDU data block viewed as int32)."""
+    L = _lib.load()
+    for n, t in (("img", img), ("agn", agn), ("bkg", bkg)):
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype != img.dtype or tuple(t.shape) != tuple(img.shape) or not t.is_contiguous():
+            raise XsdError(f"{n} must be a contiguous CUDA tensor with img's dtype and shape")
+    if img.dtype not in (torch.int32, torch.float32):
+        raise XsdError("img must be int32 or float32")
+    if mask is not None and (mask.dtype != torch.uint8 or not mask.is_cuda or tuple(mask.shape) != tuple(img.shape[-2:])):
+        raise XsdError("mask must be a CUDA uint8 tensor [Hin,Win]")
+    B, Hin, Win = img.shape
+    out = torch.empty((B, 1, res, res), device=img.device, dtype=torch.float32)
+    check(L.xsd_compose_input(img.data_ptr(), agn.data_ptr() if agn is not None else None,
+                              bkg.data_ptr() if bkg is not None else None, int(img.dtype == torch.int32), int(big_endian),
+                              mask.data_ptr() if mask is not None else None, out.data_ptr(), B, Hin, Win, int(upsample), res,
+                              int(max_val is not None), float(max_val or 0.0), STRETCH[stretch], _stream_ptr(img.device)))
+    return out
+
+
 def normalize(img: torch.Tensor, max_val: float, stretch: str, inverse: bool = False) -> torch.Tensor:
     L = _lib.load()
     _require_cuda_f32(img, "img")
