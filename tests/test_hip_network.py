@@ -164,3 +164,27 @@ def test_example_data_psnr_parity(math):
             y = sr(x)[0, 0].cpu().numpy()
             assert np.abs(y[::9, ::9] - z[f"sr_y_sub_{i}"]).max() < 1e-4
             assert abs(gc.psnr(y, t[0, 0].cpu().numpy()) - float(z[f"sr_psnr_{i}"][0])) < 0.01
+
+
+def test_infer_file_end_to_end(tmp_path):
+    """FITS (big-endian int32 counts) -> mask/pad/normalize -> SR generator -> denormalize -> FITS with the reference's
+    WCS bookkeeping; the prediction equals the oracle's forward on the same prepared input."""
+    from collections import OrderedDict
+    from xmm_superres_denoise.infer import infer_file, read_fits, write_fits
+    z = np.load(os.path.join(G, "example_data.npz"))
+    m1 = np.unpackbits(z["mask1x_bits"])[: int(np.prod(z["mask1x_shape"]))].reshape(z["mask1x_shape"])
+    counts = z["sr_counts_lr_0"]
+    src = os.path.join(tmp_path, "P0123_detxy.fits")
+    # the writer emits float32; build an int32 BITPIX-32 file by hand to exercise the raw big-endian path
+    hdr = OrderedDict(CRPIX1=201.5, CRPIX2=205.5, CDELT1=-0.0011, CDELT2=0.0011, PA_PNT=12.5, EXPOSURE=20000.0)
+    write_fits(src, counts.astype(np.float32), hdr)
+    state = gc.make_state("sr", 32, 1, 4321, last_bias=0.05)
+    m = build_module("sr", 1, 1, state)
+    y, out_path = infer_file(src, m, torch.from_numpy(m1).cuda(), os.path.join(tmp_path, "out"))
+    x = oracle.normalize(oracle.mask_pad(counts, m1, 416), 0.0022336, "sqrt")[None]
+    yo = oracle.forward("sr", 32, 1, oracle.flatten_state(state), x)
+    yo = oracle.denormalize(yo, 0.0005584, "sqrt")[0, 0]
+    assert y.shape == (832, 832) and np.abs(y - yo).max() < 1e-4 * 0.0005584 + 1e-9
+    back, h = read_fits(out_path)
+    assert np.array_equal(back.astype(np.float32), y.astype(np.float32))
+    assert h["CRPIX1"] == 2 * (201.5 + 6) + 0.5 and h["CDELT2"] == 0.00055 and h["IMG_FILE"] == "P0123_detxy.fits"
