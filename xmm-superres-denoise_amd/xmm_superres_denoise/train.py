@@ -1,0 +1,93 @@
+"""Training driver: the engine-side counterpart of the reference's `train.py fit` (train.py:19-171) for the two RRDB
+models, without Lightning.  One process per GPU (launch with torch.distributed.run for N > 1); data parallelism and the
+optimizer are `parallel.DataParallelTrainer` (flat-buffer RCCL all-reduce overlapped with backward + fused Adam).
+
+The data feed here is the reference's `BoringDataset` analogue (random tensors of the configured shapes,
+data/dataset.py:52-74): file discovery / FITS matching (`XmmDataset.__init__`) is host I/O outside the hot path; real
+samples are composed on the GPU with `engine.compose_input` (img + agn + background, mask, pad, normalize).
+
+Checkpoints use the reference's Lightning layout: {"state_dict": {"model.<key>": tensor}} with the reference key names,
+so `Model.load_from_checkpoint`-style consumers (utils/run_inference_on_file.py:28-35) can read them.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+
+import torch
+import torch.distributed as dist
+
+from xmm_superres_denoise.config.config import model_cfg
+from xmm_superres_denoise.models import Model
+from xmm_superres_denoise.parallel import DataParallelTrainer
+
+
+def save_checkpoint(path: str, model: Model, trainer: DataParallelTrainer, epoch: int) -> None:
+    sd = {"model." + k: v.detach().cpu() for k, v in model.model.state_dict().items()}
+    torch.save({"state_dict": sd, "epoch": epoch, "global_step": trainer.step_count,
+                "adam": {"m": trainer.m.cpu(), "v": trainer.v.cpu(), "step": trainer.step_count}}, path)
+
+
+def load_checkpoint(path: str, model: Model, trainer: DataParallelTrainer | None = None) -> dict:
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    sd = {k[len("model."):]: v for k, v in ck["state_dict"].items() if k.startswith("model.")}
+    if model.model is None:
+        model.configure_model()
+    model.model.load_state_dict(sd)
+    if trainer is not None and "adam" in ck:
+        trainer.m.copy_(ck["adam"]["m"]); trainer.v.copy_(ck["adam"]["v"]); trainer.step_count = int(ck["adam"]["step"])
+    return ck
+
+
+def fit(name: str = "rrdb_denoise", lr_res: int = 416, batch_size: int = 4, steps: int = 10, device: str | None = None,
+        checkpoint: str | None = None, seed: int = 0, math: str | None = None, log_every: int = 1):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device(device or f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    cfg = model_cfg(name, batch_size=batch_size)
+    hr_res = lr_res * (2 if name == "esr_gen" else 1)
+    torch.manual_seed(seed)
+    model = Model(cfg, (lr_res, lr_res), (hr_res, hr_res), loss=None, metrics=None, extended_metrics=None,
+                  in_metrics=None, in_extended_metrics=None)
+    model.configure_model()
+    model.to(dev)
+    if math:
+        model.model.set_math(math)
+    trainer = DataParallelTrainer(model.model, lr=cfg.optimizer.learning_rate, betas=cfg.optimizer.betas)
+    per_rank = batch_size // world if batch_size % world == 0 else batch_size
+    g = torch.Generator().manual_seed(seed + 1 + rank)
+    losses = []
+    for it in range(steps):
+        lr_img = torch.rand((per_rank, 1, lr_res, lr_res), generator=g).to(dev)   # BoringDataset analogue
+        hr_img = torch.rand((per_rank, 1, hr_res, hr_res), generator=g).to(dev)
+        loss = trainer.global_loss(trainer.train_step(lr_img, hr_img))
+        losses.append(float(loss))
+        if rank == 0 and log_every and it % log_every == 0:
+            print(f"step {it}: train/loss {losses[-1]:.6f}", flush=True)
+    if checkpoint and rank == 0:
+        save_checkpoint(checkpoint, model, trainer, epoch=0)
+    return model, trainer, losses
+
+
+def main():
+    ap = argparse.ArgumentParser(description="fit an RRDB generator on synthetic tiles with the MI355X engine")
+    ap.add_argument("routine", choices=["fit"])
+    ap.add_argument("--model", default="rrdb_denoise", choices=["rrdb_denoise", "esr_gen"])
+    ap.add_argument("--lr-res", type=int, default=416)
+    ap.add_argument("--batch-size", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--checkpoint", default=None)
+    ap.add_argument("--math", default=None, choices=[None, "fp32", "bf16x3", "bf16x3_p16"])
+    a = ap.parse_args()
+    fit(a.model, a.lr_res, a.batch_size, a.steps, checkpoint=a.checkpoint, math=a.math)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
