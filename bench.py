@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 32 at N=1, 16 at N>1; sr_fwd: 16)")
     ap.add_argument("--math", default=os.environ.get("XSD_MATH", "bf16x3_p16"), choices=["fp32", "bf16x3", "bf16x3_p16"],
                     help="MFMA math mode of the conv kernels (include/xsd.h: xsd_set_math)")
+    ap.add_argument("--input-pipeline", action="store_true",
+                    help="configs[4]: each step starts from int32 count tiles (411x403, Poisson, seed 2) and runs the fused "
+                         "detector-mask * pad * sqrt-normalize kernel on the GPU instead of reusing resident float tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the short exact-fp32 comparison run")
@@ -155,7 +158,24 @@ def main():
     trainer = DataParallelTrainer(model, lr=1e-4, betas=(0.9, 0.999))
     eng = trainer.engine
 
+    counts = mask = None
+    if args.input_pipeline:
+        import numpy as np
+        from xmm_superres_denoise.engine import compose_input
+        rngc = np.random.default_rng(2 + rank)
+        counts = torch.from_numpy(rngc.poisson(0.1, size=(B, 411, 403)).astype(np.int32)).to(dev)
+        gold = os.path.join(ROOT, "tests", "golden", "example_data.npz")
+        z = np.load(gold)
+        m1 = np.unpackbits(z["mask1x_bits"])[: int(np.prod(z["mask1x_shape"]))].reshape(z["mask1x_shape"])
+        mask = torch.from_numpy(m1).to(dev)
+
     def step():
+        if args.input_pipeline:
+            xin = compose_input(counts, None, None, mask, TILE, 0.0022336, "sqrt")  # 411x403 -> centred pad to 512
+            if train:
+                return trainer.train_step(xin, tgt)
+            with torch.no_grad():
+                return model(xin)
         if train:
             return trainer.train_step(x, tgt)
         with torch.no_grad():

@@ -215,3 +215,35 @@ def test_train_driver_overfits_fixed_batch_and_checkpoints(tmp_path):
     m2.cuda()
     with torch.no_grad():
         assert torch.equal(m2(x), model(x))
+
+
+def test_full_size_properties():
+    """BASELINE-size tiles (1x512x512, full 4-block DN) where the oracle is too slow: size-independent properties.
+    (a) determinism: two runs are bit-identical; (b) batch independence: a tile's output does not depend on its batch
+    neighbours (bitwise); (c) the three math modes agree within 1e-4 (tolerance 1e-3); (d) the backward pass is linear
+    in dy: grads(2*dy) == 2*grads(dy) up to rounding; (e) outputs are clamped to [0,1]."""
+    state = gc.make_state("dn", 32, 4, 2024)
+    x = torch.from_numpy(gc.make_input((2, 1, 512, 512), 2025)).cuda()
+    ys = {}
+    for math in MATHS:
+        m = build_module("dn", 4, 1, state).set_math(math)
+        with torch.no_grad():
+            y1 = m(x)
+            y2 = m(x)
+            y_single = m(x[1:2].contiguous())
+        assert torch.equal(y1, y2), math
+        assert torch.equal(y1[1:2], y_single), math
+        assert float(y1.min()) >= 0.0 and float(y1.max()) <= 1.0
+        ys[math] = y1
+        if math == "fp32":
+            eng = m._get_engine(torch.device("cuda", 0))
+            eng.pack(m.flat_parameters())
+            y = eng.forward(x, save_for_backward=True)
+            dy = torch.from_numpy(gc.make_input((2, 1, 512, 512), 2026) - 0.5).cuda() / x.numel()
+            g1 = torch.empty_like(m.flat_parameters())
+            g2 = torch.empty_like(g1)
+            eng.backward(dy, g1)
+            eng.backward((2.0 * dy).contiguous(), g2)
+            assert float((g2 - 2.0 * g1).abs().max()) <= 1e-5 * float(g1.abs().max())
+    assert float((ys["bf16x3"] - ys["fp32"]).abs().max()) < 1e-4
+    assert float((ys["bf16x3_p16"] - ys["fp32"]).abs().max()) < 1e-4
