@@ -95,6 +95,27 @@ int xsd_grad_range(const xsd_engine* e, int stage, int range_idx, int64_t* offse
 int xsd_l1_loss(xsd_engine* e, const float* dev_y, const float* dev_target, float* dev_dy_or_null, float* dev_loss,
                 int64_t n, void* stream);
 
+/* replaces create_loss + the per-batch Metric.forward of the composed loss (utils/loss_functions.py:11-47;
+ * models/model.py:78; constants res/configs/loss_functions.toml:5-42).  w_* are the EFFECTIVE weights of the terms
+ * (relative percentage x paper scaling; 0 = term absent), correction is added to the total when > 0
+ * (loss_functions.py:44-45).  ssim / ms_ssim follow torchmetrics 1.x with gaussian_kernel=True: window
+ * int(3.5*sigma+0.5)*2+1 taps, data_range from the images, k1/k2 as given, kernel_size only for the MS-SSIM size check
+ * (the reference passes kernel_size=13, sigma=2.5, k2=0.05; k1 defaults to 0.01).  psnr/ssim/ms_ssim parity is unpinned
+ * (torchmetrics absent here); see oracle/loss.py for the restated algorithm.
+ * y, target: [B][H][W].  dev_out8 (device floats): [0] total, [1] l1, [2] poisson, [3] psnr, [4] ssim, [5] ms_ssim
+ * (inactive terms 0).  dev_dy_or_null receives d total / d y. */
+typedef struct xsd_loss_config {
+    float w_l1, w_poisson, w_psnr, w_ssim, w_ms_ssim;
+    float correction;
+    float sigma, k1, k2;
+    int32_t kernel_size;
+} xsd_loss_config;
+typedef struct xsd_loss_fn xsd_loss_fn;   /* the object create_loss returns; owns a device workspace */
+int xsd_loss_create(const xsd_loss_config* cfg, xsd_loss_fn** out);
+void xsd_loss_destroy(xsd_loss_fn* f);
+int xsd_loss_eval(xsd_loss_fn* f, const float* dev_y, const float* dev_target, float* dev_dy_or_null, float* dev_out8,
+                  int B, int H, int W, void* stream);
+
 /* torch.optim.Adam(lr, betas, eps=1e-8) single fused step over flat buffers (models/model.py:241-245).
  * step is 1-based; grad_scale multiplies the gradient on read (1/world_size for data-parallel mean). */
 int xsd_adam_step(xsd_engine* e, float* dev_params, const float* dev_grads, float* dev_m, float* dev_v, int64_t n,

@@ -1,0 +1,153 @@
+"""GPU parity of the loss kernels (xsd_loss_eval through the C ABI) against the CPU oracle (oracle/loss.py) and the
+committed autograd goldens.  Tolerances: values 2e-6 relative (fp32 maps, float64 sums), gradients 2e-5 of the largest
+gradient entry (fp32 stencils against the float64 oracle)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import make_golden_loss as mg
+from oracle import loss as ol
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss.npz"))
+VAL_RTOL, GRAD_TOL = 2e-6, 2e-5
+
+
+def _run(weights, corr, p, t, want_grad=True):
+    from xmm_superres_denoise.utils import Loss
+    f = Loss(weights, corr)
+    pc, tc = torch.from_numpy(p).cuda(), torch.from_numpy(t).cuda()
+    if want_grad:
+        tot, dy = f.value_and_grad(pc, tc)
+        return tot.item(), f.term_values(), dy.cpu().numpy()
+    out, _ = f._eval(pc, tc, False)
+    f.last_values = out
+    return out[0].item(), f.term_values(), None
+
+
+@pytest.mark.parametrize("case", sorted(mg.CASES))
+@pytest.mark.parametrize("term", ol.TERMS)
+def test_single_term_matches_oracle_and_golden(case, term):
+    B, H, W, seed = mg.CASES[case]
+    p, t = mg.loss_inputs(B, H, W, seed)
+    tot, vals, dy = _run({term: 1.0}, 0.0, p, t)
+    v, g = ol._FUNCS[term](p, t)
+    assert abs(vals[term] - v) <= VAL_RTOL * max(1.0, abs(v))
+    assert abs(tot - v) <= VAL_RTOL * max(1.0, abs(v))
+    assert abs(vals[term] - G[f"{case}_{term}_f64_value"]) <= VAL_RTOL * max(1.0, abs(v))
+    scale = np.abs(g).max()
+    assert np.abs(dy - g).max() <= GRAD_TOL * scale
+    assert np.abs(dy[:, ::mg.SUB, ::mg.SUB] - G[f"{case}_{term}_f64_grad_sub"]).max() <= GRAD_TOL * scale
+    # forward-only call gives the same value and writes no gradient
+    tot2, _, none = _run({term: 1.0}, 0.0, p, t, want_grad=False)
+    assert none is None and tot2 == tot
+
+
+def test_reference_default_loss_composition():
+    """loss_functions.toml defaults: 0.5 psnr + 0.5 ms_ssim with the 'linear' scaling table and summed corrections"""
+    from xmm_superres_denoise.utils import create_loss, load_loss_config
+    sc, cfg = load_loss_config("linear")
+    loss = create_loss(sc, cfg)
+    w, corr = ol.effective_weights(cfg.model_dump(), sc)
+    assert {k: v for k, v in loss.weights.items() if v != 0.0} == pytest.approx(w)
+    B, H, W, seed = mg.CASES["a"]
+    p, t = mg.loss_inputs(B, H, W, seed)
+    total, values, grad = ol.loss_and_grad(p, t, w, corr)
+    pc = torch.from_numpy(p).cuda()[:, None].requires_grad_(True)
+    tc = torch.from_numpy(t).cuda()[:, None]
+    out = loss(pc, tc)                      # autograd surface, NCHW with C = 1 like the reference's tensors
+    (out * 3.0).backward()
+    assert abs(out.item() - total) <= 5e-6 * abs(total)
+    assert np.abs(pc.grad[:, 0].cpu().numpy() - 3.0 * grad).max() <= GRAD_TOL * 3.0 * np.abs(grad).max()
+    assert set(loss.term_values()) == {"total", "psnr", "ms_ssim"}
+
+
+def test_all_terms_together_and_correction_rule():
+    B, H, W, seed = mg.CASES["b"]
+    p, t = mg.loss_inputs(B, H, W, seed)
+    w = {"l1": 0.3, "poisson": 0.01, "psnr": -0.02, "ssim": -0.4, "ms_ssim": -0.5}
+    for corr in (1.25, -0.5):               # a non-positive correction sum is dropped (loss_functions.py:44)
+        tot, vals, dy = _run(w, corr, p, t)
+        total, values, grad = ol.loss_and_grad(p, t, w, corr)
+        assert abs(tot - total) <= 5e-6 * max(1.0, abs(total))
+        for k in w:
+            assert abs(vals[k] - values[k]) <= VAL_RTOL * max(1.0, abs(values[k]))
+        assert np.abs(dy - grad).max() <= GRAD_TOL * np.abs(grad).max()
+
+
+def test_ragged_sizes_and_data_range_from_target():
+    """odd sizes (pooling drops the last row/column, tiles are ragged) and a target with the wider range, in which case
+    data_range carries no gradient"""
+    rng = np.random.Generator(np.random.PCG64(5))
+    B, H, W = 2, 307, 333
+    t = rng.random((B, H, W)).astype(np.float32)
+    p = np.clip(0.1 + 0.8 * t + 0.05 * rng.standard_normal((B, H, W)), 0.05, 0.95).astype(np.float32)
+    for term in ("ssim", "ms_ssim"):
+        tot, vals, dy = _run({term: 1.0}, 0.0, p, t)
+        v, g = ol._FUNCS[term](p, t)
+        assert abs(vals[term] - v) <= VAL_RTOL
+        # 307 -> 19 pixels at the coarsest scale leaves a 1 x 2 interior: its whole gradient funnels through two fp32
+        # variance differences, so the bound against the float64 oracle is looser here
+        assert np.abs(dy - g).max() <= 5 * GRAD_TOL * np.abs(g).max()
+
+
+def test_error_behaviour():
+    from xmm_superres_denoise.engine._lib import XsdError
+    from xmm_superres_denoise.utils import Loss
+    with pytest.raises(XsdError):
+        Loss({"l1": 0.0})                                    # `assert metrics`
+    f = Loss({"ms_ssim": 1.0})
+    small = torch.rand(1, 1, 128, 128, device="cuda")
+    with pytest.raises(XsdError):                            # torchmetrics raises ValueError for 128 // 16 <= 12
+        f(small, small.clone())
+    with pytest.raises(XsdError):
+        Loss({"l1": 1.0})(torch.rand(1, 1, 8, 8), torch.rand(1, 1, 8, 8))   # CPU tensors: no fallback
+
+
+def test_full_size_properties():
+    """512 x 512, batch 8: identical images give ssim = ms_ssim = 1 and a vanishing gradient; the composed value is
+    linear in the weights; the result is bit-reproducible (deterministic reductions)."""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    t = torch.rand(8, 1, 512, 512, generator=g).cuda()
+    p = (t + 0.05 * torch.randn(8, 1, 512, 512, generator=g).cuda()).clamp(0, 1)
+    from xmm_superres_denoise.utils import Loss
+    one = Loss({"ssim": 1.0, "ms_ssim": 1.0})
+    tot, dy = one.value_and_grad(t.clone(), t)
+    v = one.term_values()
+    assert abs(v["ssim"] - 1.0) < 1e-6 and abs(v["ms_ssim"] - 1.0) < 1e-6 and dy.abs().max().item() < 1e-7
+    a = Loss({"psnr": 1.0}); b = Loss({"ms_ssim": 1.0}); ab = Loss({"psnr": 0.25, "ms_ssim": -2.0}, 0.5)
+    va, ga = a.value_and_grad(p, t); vb, gb = b.value_and_grad(p, t); vab, gab = ab.value_and_grad(p, t)
+    assert abs(vab.item() - (0.25 * va.item() - 2.0 * vb.item() + 0.5)) < 1e-4
+    assert (gab - (0.25 * ga - 2.0 * gb)).abs().max().item() <= 1e-6 * gab.abs().max().item()
+    vab2, gab2 = ab.value_and_grad(p, t)
+    assert vab2.item() == vab.item() and torch.equal(gab, gab2)
+
+
+def test_paper_loss_drives_training_and_autograd_path_agrees():
+    """The reference's shipped default loss (0.5 psnr + 0.5 ms_ssim, scaled) through both host surfaces: the autograd
+    surface (Model.training_step -> loss(preds, target).backward(), models/model.py:72-86) gives the same parameter
+    gradients as the fused trainer path, and a few Adam steps on a fixed batch lower the loss."""
+    from xmm_superres_denoise.config.config import model_cfg
+    from xmm_superres_denoise.models import Model
+    from xmm_superres_denoise.parallel import DataParallelTrainer
+    from xmm_superres_denoise.utils import create_loss, load_loss_config
+    torch.manual_seed(0)
+    loss = create_loss(*load_loss_config("linear"))
+    model = Model(model_cfg("rrdb_denoise", batch_size=2, residual_blocks=1), (320, 320), (320, 320), loss, None, None, None, None)
+    model.configure_model()
+    model.cuda()
+    p_np, t_np = mg.loss_inputs(2, 320, 320, 21)
+    x, t = torch.from_numpy(p_np).cuda()[:, None], torch.from_numpy(t_np).cuda()[:, None]
+    out = model.training_step((x, t))
+    out.backward()
+    g_autograd = torch.cat([p.grad.reshape(-1) for p in model.model.parameters()])
+    tr = DataParallelTrainer(model.model, lr=2e-4, loss=loss)
+    before = tr.flat.clone()
+    first = float(tr.train_step(x, t))
+    assert abs(first - out.item()) <= 1e-6 * abs(first)
+    assert torch.equal(tr.grads, g_autograd)
+    assert not torch.equal(before, tr.flat)
+    losses = [first] + [float(tr.train_step(x, t)) for _ in range(10)]
+    assert losses[-1] < losses[0]

@@ -17,10 +17,12 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <new>
 #include <vector>
 
 #include "../../include/xsd.h"
 #include "xsd_aux.h"
+#include "xsd_loss.h"
 #include "xsd_kernels.h"
 
 using namespace xsd;
@@ -710,6 +712,54 @@ int xsd_l1_loss(xsd_engine* e, const float* dev_y, const float* dev_target, floa
 {
     if (!e || !dev_y || !dev_target || !dev_loss || n <= 0) return fail(XSD_ERR_ARG, "bad argument");
     HIPCHK(launch_l1_loss(dev_y, dev_target, dev_dy_or_null, e->loss_partial, 1024, dev_loss, n, (hipStream_t)stream));
+    return XSD_OK;
+}
+
+struct xsd_loss_fn {
+    LossWeights w;
+    void* ws = nullptr;      // workspace, grown on demand
+    size_t ws_bytes = 0;
+};
+
+int xsd_loss_create(const xsd_loss_config* cfg, xsd_loss_fn** out)
+{
+    if (!cfg || !out) return fail(XSD_ERR_ARG, "bad argument");
+    LossWeights w;
+    w.w[0] = cfg->w_l1; w.w[1] = cfg->w_poisson; w.w[2] = cfg->w_psnr; w.w[3] = cfg->w_ssim; w.w[4] = cfg->w_ms_ssim;
+    w.correction = cfg->correction; w.sigma = cfg->sigma; w.k1 = cfg->k1; w.k2 = cfg->k2; w.kernel_size = cfg->kernel_size;
+    bool any = false;
+    for (int i = 0; i < 5; ++i) any = any || w.w[i] != 0.f;
+    if (!any) return fail(XSD_ERR_ARG, "loss: no term has a non-zero weight");   // `assert metrics` (loss_functions.py:38)
+    if ((w.w[3] != 0.f || w.w[4] != 0.f) && !(w.sigma > 0.f)) return fail(XSD_ERR_ARG, "loss: sigma must be > 0");
+    xsd_loss_fn* f = new (std::nothrow) xsd_loss_fn();
+    if (!f) return fail(XSD_ERR_NOMEM, "out of host memory");
+    f->w = w;
+    *out = f;
+    return XSD_OK;
+}
+
+void xsd_loss_destroy(xsd_loss_fn* f)
+{
+    if (!f) return;
+    hipFree(f->ws);
+    delete f;
+}
+
+int xsd_loss_eval(xsd_loss_fn* f, const float* dev_y, const float* dev_target, float* dev_dy_or_null, float* dev_out8, int B, int H,
+                  int W, void* stream)
+{
+    if (!f || !dev_y || !dev_target || !dev_out8) return fail(XSD_ERR_ARG, "bad argument");
+    const char* why = nullptr;
+    if (loss_check(f->w, B, H, W, &why)) return fail(XSD_ERR_ARG, why);
+    const size_t need = loss_workspace_bytes(B, H, W);
+    if (need > f->ws_bytes) {
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        if (f->ws) HIPCHK(hipFree(f->ws));
+        f->ws = nullptr; f->ws_bytes = 0;
+        if (hipMalloc(&f->ws, need) != hipSuccess) return fail(XSD_ERR_NOMEM, "loss workspace allocation failed");
+        f->ws_bytes = need;
+    }
+    HIPCHK(launch_loss(f->w, dev_y, dev_target, dev_dy_or_null, dev_out8, B, H, W, f->ws, (hipStream_t)stream));
     return XSD_OK;
 }
 

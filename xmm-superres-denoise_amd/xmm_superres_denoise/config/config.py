@@ -3,7 +3,7 @@
 from enum import Enum
 from typing import Literal, Tuple
 
-from pydantic import BaseModel, NonNegativeFloat, PositiveInt
+from pydantic import BaseModel, Field, NonNegativeFloat, PositiveInt, model_validator
 
 
 class BaseModels(str, Enum):
@@ -56,3 +56,26 @@ def model_cfg(name: str, batch_size: int = 1, memory_efficient: bool = False, **
     opt = OptimizerCfg(learning_rate=d.pop("learning_rate"), betas=tuple(d.pop("betas")))
     return ModelCfg(name=BaseModels(name), memory_efficient=memory_efficient, batch_size=batch_size,
                     model=RrdbCfg(**d), optimizer=opt)
+
+
+class ConfigError(Exception):
+    """reference config/config.py:19-21"""
+
+    def __init__(self, message: str = ""):
+        super().__init__(message)
+
+
+class LossCfg(BaseModel):
+    """reference config/config.py:222-237: relative percentages of the loss terms, 0 < sum <= 1"""
+    l1: float = Field(ge=0, le=1)
+    poisson: float = Field(ge=0, le=1)
+    psnr: float = Field(ge=0, le=1)
+    ssim: float = Field(ge=0, le=1)
+    ms_ssim: float = Field(ge=0, le=1)
+
+    @model_validator(mode="after")
+    def check_sum(self):
+        p_sum = self.l1 + self.poisson + self.psnr + self.ssim + self.ms_ssim
+        if 0 < p_sum <= 1:
+            return self
+        raise ConfigError(f"Sum of relative percentages has to be between 0 and 1, got {p_sum}!")

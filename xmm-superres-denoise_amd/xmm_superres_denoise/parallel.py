@@ -18,8 +18,11 @@ import torch.distributed as dist
 
 class DataParallelTrainer:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, engine=None,
-                 process_group=None):
+                 process_group=None, loss=None):
+        """loss: None = mean L1 (BASELINE configs[2]); or the object `utils.create_loss` returns (the reference's
+        composed PSNR / MS-SSIM / ... loss, utils/loss_functions.py:11-47), evaluated by xsd_loss_eval."""
         self.model = model
+        self.loss = loss
         self.lr, self.betas, self.eps = lr, tuple(betas), eps
         self.flat = model.flat_parameters()
         self.engine = engine if engine is not None else model._get_engine(self.flat.device)
@@ -46,7 +49,7 @@ class DataParallelTrainer:
         eng = self.engine
         eng.pack(self.flat)
         y = eng.forward(x, save_for_backward=True)
-        loss, dy = eng.l1_loss(y, target)
+        loss, dy = eng.l1_loss(y, target) if self.loss is None else self.loss.value_and_grad(y, target)
         works = []
         for st in range(eng.num_stages):
             eng.backward_stage(st, dy, self.grads)

@@ -40,7 +40,10 @@ def load_checkpoint(path: str, model: Model, trainer: DataParallelTrainer | None
 
 
 def fit(name: str = "rrdb_denoise", lr_res: int = 416, batch_size: int = 4, steps: int = 10, device: str | None = None,
-        checkpoint: str | None = None, seed: int = 0, math: str | None = None, log_every: int = 1):
+        checkpoint: str | None = None, seed: int = 0, math: str | None = None, log_every: int = 1,
+        loss: str = "l1", scaling: str = "linear"):
+    """loss: "l1" (BASELINE configs[2]) or "paper" = the reference's shipped default, 0.5 psnr + 0.5 ms_ssim with the
+    scaling table of the dataset's stretch mode (`scaling`; res/configs/loss_functions.toml, train.py:46-63)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -52,13 +55,17 @@ def fit(name: str = "rrdb_denoise", lr_res: int = 416, batch_size: int = 4, step
     cfg = model_cfg(name, batch_size=batch_size)
     hr_res = lr_res * (2 if name == "esr_gen" else 1)
     torch.manual_seed(seed)
-    model = Model(cfg, (lr_res, lr_res), (hr_res, hr_res), loss=None, metrics=None, extended_metrics=None,
+    loss_fn = None
+    if loss != "l1":
+        from xmm_superres_denoise.utils import create_loss, load_loss_config
+        loss_fn = create_loss(*load_loss_config(scaling))
+    model = Model(cfg, (lr_res, lr_res), (hr_res, hr_res), loss=loss_fn, metrics=None, extended_metrics=None,
                   in_metrics=None, in_extended_metrics=None)
     model.configure_model()
     model.to(dev)
     if math:
         model.model.set_math(math)
-    trainer = DataParallelTrainer(model.model, lr=cfg.optimizer.learning_rate, betas=cfg.optimizer.betas)
+    trainer = DataParallelTrainer(model.model, lr=cfg.optimizer.learning_rate, betas=cfg.optimizer.betas, loss=loss_fn)
     per_rank = batch_size // world if batch_size % world == 0 else batch_size
     g = torch.Generator().manual_seed(seed + 1 + rank)
     losses = []
@@ -83,8 +90,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--checkpoint", default=None)
     ap.add_argument("--math", default=None, choices=[None, "fp32", "bf16x3", "bf16x3_p16"])
+    ap.add_argument("--loss", default="l1", choices=["l1", "paper"], help="paper = 0.5 psnr + 0.5 ms_ssim (loss_functions.toml)")
+    ap.add_argument("--scaling", default="linear", choices=["linear", "sqrt", "asinh", "log"])
     a = ap.parse_args()
-    fit(a.model, a.lr_res, a.batch_size, a.steps, checkpoint=a.checkpoint, math=a.math)
+    fit(a.model, a.lr_res, a.batch_size, a.steps, checkpoint=a.checkpoint, math=a.math, loss=a.loss, scaling=a.scaling)
     if dist.is_initialized():
         dist.destroy_process_group()
 

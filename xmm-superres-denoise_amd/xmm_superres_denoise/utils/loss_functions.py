@@ -1,0 +1,142 @@
+"""Host mirror of the reference's loss factory (xmm_superres_denoise/utils/loss_functions.py:11-47).
+
+`create_loss(sc_dict, loss_config)` keeps the reference's signature and arithmetic: for every term with a relative
+percentage p > 0, weight = p * scaling (when a scaling table is given) and the corrections are summed; the result is
+`sum_i weight_i * metric_i(preds, target)` plus the correction when that sum is > 0.  What it returns is a `Loss`: a
+callable `(preds, target) -> scalar tensor` (like the torchmetrics CompositionalMetric's forward, models/model.py:78),
+differentiable with respect to preds, evaluated entirely by the HIP kernels behind `xsd_loss_eval` (include/xsd.h).
+There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from ..config.config import LossCfg
+from ..engine._lib import XsdError, check, load
+from ..engine.engine import _require_cuda_f32, _stream_ptr
+
+TERMS = ("l1", "poisson", "psnr", "ssim", "ms_ssim")
+
+# res/configs/loss_functions.toml:5-42 of the reference: default percentages and the paper's scaling/correction tables
+LOSS_TOML = {
+    "loss": dict(use_scaling=True, l1=0.0, poisson=0.0, psnr=0.5, ssim=0.0, ms_ssim=0.5),
+    "scaling": {
+        "linear": {"l1": (27.404768429706774, -0.5746779939709512), "poisson": (6.583278472679395, -1.187623436471363),
+                   "psnr": (-0.11938872970391594, 3.6491165234001905), "ssim": (-2.97441998810232, 2.1469363474122547),
+                   "ms_ssim": (-2.85143997718848, 2.737382378100941)},
+        "sqrt": {"l1": (9.65623792970259, -0.5189262263422172), "poisson": (12.269938650306754, -5.137423312883438),
+                 "psnr": (-0.121713729308666, 2.7966163583252186), "ssim": (-3.0684258975145746, 1.417919607241485),
+                 "ms_ssim": (-3.0165912518853695, 2.636500754147813)},
+        "asinh": {"l1": (5.651952749675013, -0.4542474424913807), "poisson": (0.4388467108439022, -0.22920963707377018),
+                  "psnr": (-0.11042402826855124, 2.1554770318021204), "ssim": (-3.2824552765468566, 1.2020351222714591),
+                  "ms_ssim": (-1.6189088554314395, 1.3368949328152826)},
+        "log": {"l1": (4.071661237785016, -0.4364820846905537), "poisson": (0.39835876190096803, -0.2616021989403656),
+                "psnr": (-0.1108524553818867, 1.8665336437202082), "ssim": (-3.414600833162603, 1.176671447107833),
+                "ms_ssim": (-2.043318348998774, 1.6309767061708214)},
+    },
+}
+
+
+class _LossConfigC(ctypes.Structure):
+    _fields_ = [("w_l1", ctypes.c_float), ("w_poisson", ctypes.c_float), ("w_psnr", ctypes.c_float),
+                ("w_ssim", ctypes.c_float), ("w_ms_ssim", ctypes.c_float), ("correction", ctypes.c_float),
+                ("sigma", ctypes.c_float), ("k1", ctypes.c_float), ("k2", ctypes.c_float), ("kernel_size", ctypes.c_int32)]
+
+
+def load_loss_config(scaling: str = "linear", **overrides):
+    """What train.py:46-53 of the reference does with loss_functions.toml: returns (sc_dict | None, LossCfg)."""
+    d = dict(LOSS_TOML["loss"])
+    d.update(overrides)
+    sc = None
+    if d.pop("use_scaling"):
+        sc = {k: {"scaling": v[0], "correction": v[1]} for k, v in LOSS_TOML["scaling"][scaling].items()}
+    return sc, LossCfg(**d)
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, preds, target, loss, need_grad):
+        out, dy = loss._eval(preds, target, need_grad)
+        loss.last_values = out
+        if need_grad:
+            ctx.save_for_backward(dy)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dy,) = ctx.saved_tensors
+        return dy * g, None, None, None
+
+
+class Loss:
+    """weights: {term: effective weight}; correction: summed corrections (added when > 0, loss_functions.py:44-45)."""
+
+    def __init__(self, weights: dict, correction: float = 0.0, kernel_size: int = 13, sigma: float = 2.5,
+                 k1: float = 0.01, k2: float = 0.05):
+        unknown = set(weights) - set(TERMS)
+        if unknown:
+            raise XsdError(f"unknown loss terms {sorted(unknown)}")
+        self.weights = {k: float(weights.get(k, 0.0)) for k in TERMS}
+        self.correction = float(correction)
+        self.L = load()
+        cfg = _LossConfigC(*[self.weights[k] for k in TERMS], self.correction, sigma, k1, k2, kernel_size)
+        h = ctypes.c_void_p()
+        check(self.L.xsd_loss_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self.h = h
+        self.last_values = None   # device tensor [8]: total, l1, poisson, psnr, ssim, ms_ssim of the last call
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.xsd_loss_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def _eval(self, preds, target, want_grad):
+        _require_cuda_f32(preds, "preds")
+        _require_cuda_f32(target, "target")
+        if preds.shape != target.shape:
+            raise XsdError(f"shape mismatch {tuple(preds.shape)} vs {tuple(target.shape)}")
+        if preds.dim() == 4 and preds.shape[1] == 1:
+            B, _, H, W = preds.shape
+        elif preds.dim() == 3:
+            B, H, W = preds.shape
+        else:
+            raise XsdError(f"expected [B,1,H,W] or [B,H,W], got {tuple(preds.shape)}")
+        out = torch.empty(8, device=preds.device, dtype=torch.float32)
+        dy = torch.empty_like(preds) if want_grad else None
+        check(self.L.xsd_loss_eval(self.h, preds.data_ptr(), target.data_ptr(), dy.data_ptr() if want_grad else None,
+                                   out.data_ptr(), B, H, W, _stream_ptr(preds.device)))
+        return out, dy
+
+    def value_and_grad(self, preds, target):
+        """engine-level call used by the training driver: (total [scalar tensor], d total / d preds)"""
+        out, dy = self._eval(preds, target, True)
+        self.last_values = out
+        return out[0], dy
+
+    def __call__(self, preds: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        need = torch.is_grad_enabled() and preds.requires_grad
+        return _LossFn.apply(preds, target, self, need)
+
+    def term_values(self) -> dict:
+        v = self.last_values.tolist()
+        return {"total": v[0], **{k: v[1 + i] for i, k in enumerate(TERMS) if self.weights[k] != 0.0}}
+
+    def __repr__(self):
+        terms = " + ".join(f"{w:g}*{k}" for k, w in self.weights.items() if w != 0.0)
+        return f"Loss({terms}{f' + {self.correction:g}' if self.correction > 0 else ''})"
+
+
+def create_loss(sc_dict: dict | None, loss_config: LossCfg) -> Loss:
+    """reference signature: create_loss(sc_dict: dict[str, dict[str, float]] | None, loss_config: LossCfg) -> Metric"""
+    correction = 0.0
+    weights = {}
+    for loss, p in iter(loss_config):
+        if p > 0.0:
+            if sc_dict is not None and loss in sc_dict:
+                p = p * sc_dict[loss]["scaling"]
+                correction = correction + sc_dict[loss]["correction"]
+            weights[loss] = p
+    assert weights
+    return Loss(weights, correction)
