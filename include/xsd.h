@@ -102,8 +102,11 @@ int xsd_l1_loss(xsd_engine* e, const float* dev_y, const float* dev_target, floa
  * int(3.5*sigma+0.5)*2+1 taps, data_range from the images, k1/k2 as given, kernel_size only for the MS-SSIM size check
  * (the reference passes kernel_size=13, sigma=2.5, k2=0.05; k1 defaults to 0.01).  psnr/ssim/ms_ssim parity is unpinned
  * (torchmetrics absent here); see oracle/loss.py for the restated algorithm.
- * y, target: [B][H][W].  dev_out8 (device floats): [0] total, [1] l1, [2] poisson, [3] psnr, [4] ssim, [5] ms_ssim
- * (inactive terms 0).  dev_dy_or_null receives d total / d y. */
+ * y, target: [B][H][W].  dev_out (XSD_LOSS_OUT = 12 device floats): [0] total, [1] l1, [2] poisson, [3] psnr, [4] ssim,
+ * [5] ms_ssim (inactive terms 0), [6] mean squared error, [7] min(target), [8] max(target) (the last three when any of
+ * l1 / poisson / psnr is active; they are the per-batch states the epoch-level metrics accumulate,
+ * metrics/xmm_metric_collection.py:14-38), [9..11] reserved.  dev_dy_or_null receives d total / d y. */
+#define XSD_LOSS_OUT 12
 typedef struct xsd_loss_config {
     float w_l1, w_poisson, w_psnr, w_ssim, w_ms_ssim;
     float correction;
@@ -113,7 +116,7 @@ typedef struct xsd_loss_config {
 typedef struct xsd_loss_fn xsd_loss_fn;   /* the object create_loss returns; owns a device workspace */
 int xsd_loss_create(const xsd_loss_config* cfg, xsd_loss_fn** out);
 void xsd_loss_destroy(xsd_loss_fn* f);
-int xsd_loss_eval(xsd_loss_fn* f, const float* dev_y, const float* dev_target, float* dev_dy_or_null, float* dev_out8,
+int xsd_loss_eval(xsd_loss_fn* f, const float* dev_y, const float* dev_target, float* dev_dy_or_null, float* dev_out,
                   int B, int H, int W, void* stream);
 
 /* torch.optim.Adam(lr, betas, eps=1e-8) single fused step over flat buffers (models/model.py:241-245).

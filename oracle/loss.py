@@ -212,3 +212,26 @@ def loss_and_grad(p, t, weights: dict, correction: float = 0.0, sigma=2.5, k1=0.
     if correction > 0.0:
         total += correction
     return float(total), values, grad
+
+
+def metric_epoch(batches, stretch=lambda a: a):
+    """Epoch-level values of the reference's validation metric set (metrics/xmm_metric_collection.py:14-38) over a list
+    of (preds, target) batches, accumulated the way the torchmetrics classes accumulate their states."""
+    sse = n = abs_sum = 0.0
+    tmin = tmax = 0.0
+    ssim_sum = ms_sum = po_sum = 0.0
+    nimg = 0
+    for p, t in batches:
+        p = stretch(np.asarray(p, np.float64))
+        t = stretch(np.asarray(t, np.float64))
+        d = p - t
+        sse += (d * d).sum(); abs_sum += np.abs(d).sum(); n += d.size
+        tmin, tmax = min(tmin, t.min()), max(tmax, t.max())
+        B = p.shape[0]
+        ssim_sum += ssim(p, t, want_grad=False)[0] * B
+        ms_sum += ms_ssim(p, t, want_grad=False)[0] * B
+        po_sum += poisson(p, t, want_grad=False)[0] * B
+        nimg += B
+    mse = sse / n
+    return {"psnr": 10 * np.log10((tmax - tmin) ** 2 / mse), "ssim": ssim_sum / nimg, "ms_ssim": ms_sum / nimg,
+            "l1": abs_sum / n, "l2": mse, "poisson": po_sum / nimg}

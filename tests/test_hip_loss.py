@@ -151,3 +151,29 @@ def test_paper_loss_drives_training_and_autograd_path_agrees():
     assert not torch.equal(before, tr.flat)
     losses = [first] + [float(tr.train_step(x, t)) for _ in range(10)]
     assert losses[-1] < losses[0]
+
+
+def test_validation_metric_collection_epoch_accumulation():
+    """get_metrics / get_in_metrics (metrics/xmm_metric_collection.py): two unequal batches, linear + sqrt stretch;
+    epoch values follow the torchmetrics state accumulation, not a mean of batch values."""
+    from xmm_superres_denoise.metrics import get_in_metrics, get_metrics
+    from xmm_superres_denoise.transforms import Normalize
+    ds = Normalize(lr_max=0.0022336, hr_max=0.0022336, stretch_mode="sqrt")
+    scalers = [Normalize(0.0022336, 0.0022336, m) for m in ("linear", "sqrt")]
+    mc = get_metrics(ds, scalers, "val")
+    p1, t1 = mg.loss_inputs(2, 320, 336, 31)
+    p2, t2 = mg.loss_inputs(3, 320, 336, 32)
+    t2 = (0.7 * t2).astype(np.float32)                    # different target range per batch
+    for p, t in ((p1, t1), (p2, t2)):
+        mc.update(torch.from_numpy(p).cuda()[:, None], torch.from_numpy(t).cuda()[:, None])
+    got = {k: v.item() for k, v in mc.compute().items()}
+    sq = lambda a: a * a                                   # undo the dataset's sqrt stretch
+    for mode, st in (("linear", sq), ("sqrt", lambda a: np.sqrt(sq(a)))):
+        want = ol.metric_epoch([(p1, t1), (p2, t2)], st)
+        for k, v in want.items():
+            assert abs(got[f"val/{mode}/{k}"] - v) <= 5e-6 * max(1.0, abs(v)), (mode, k, got[f"val/{mode}/{k}"], v)
+    assert set(got) == {f"val/{m}/{k}" for m in ("linear", "sqrt") for k in ("psnr", "ssim", "ms_ssim", "l1", "l2", "poisson")}
+    mc.reset()
+    mi = get_in_metrics(ds, scalers[:1], "val")
+    mi.update(torch.from_numpy(p1).cuda()[:, None], torch.from_numpy(t1).cuda()[:, None])
+    assert "val/linear/in/psnr" in mi.compute()

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(NT) void pointwise_sums_kernel(const float* p, cons
 }
 // values[0..2] = l1, poisson, psnr; values[3] = mse (for the psnr gradient)
 __global__ __launch_bounds__(NT) void pointwise_final_kernel(const double* partial, int nblocks, long long n, int B, float* v_l1,
-                                                             float* v_poisson, float* v_psnr, float* mse_out)
+                                                             float* v_poisson, float* v_psnr, float* mse_out, float* extra)
 {
     __shared__ double red[NT];
     double a = 0, b = 0, c = 0, lo = INFINITY, hi = -INFINITY;
@@ -402,6 +402,7 @@ __global__ __launch_bounds__(NT) void pointwise_final_kernel(const double* parti
         *v_poisson = (float)(b / (double)n / (double)B);
         *v_psnr = (float)((2.0 * log(dr) - log(mse)) * (10.0 / log(10.0)));
         *mse_out = (float)mse;
+        extra[0] = (float)mse; extra[1] = (float)mm[0][0]; extra[2] = (float)mm[1][0];
     }
 }
 __global__ void pointwise_grad_kernel(const float* p, const float* t, float* dy, long long n, float w_l1, float w_po, float w_ps,
@@ -546,13 +547,13 @@ hipError_t launch_loss(const LossWeights& w, const float* y, const float* t, flo
     char* ws = (char*)workspace;
     const long long n = (long long)B * H * W;
     int wrote = 0;
-    hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, s, out8, 8LL);
+    hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(64), 0, s, out8, (long long)LOSS_OUT_FLOATS);
     if (w.w[0] != 0.f || w.w[1] != 0.f || w.w[2] != 0.f) {
         double* partial = (double*)ws;
         float* mse = (float*)(ws + 5 * 1024 * sizeof(double));
         const int nb = grid_for(n, NT * 8) > 1024 ? 1024 : grid_for(n, NT * 8);
         hipLaunchKernelGGL(pointwise_sums_kernel, dim3(nb), dim3(NT), 0, s, y, t, n, partial);
-        hipLaunchKernelGGL(pointwise_final_kernel, dim3(1), dim3(NT), 0, s, partial, nb, n, B, out8 + 1, out8 + 2, out8 + 3, mse);
+        hipLaunchKernelGGL(pointwise_final_kernel, dim3(1), dim3(NT), 0, s, partial, nb, n, B, out8 + 1, out8 + 2, out8 + 3, mse, out8 + 6);
         if (dy) {
             hipLaunchKernelGGL(pointwise_grad_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, y, t, dy, n, w.w[0],
                                w.w[1] / ((float)n * (float)B), w.w[2], mse, 0);

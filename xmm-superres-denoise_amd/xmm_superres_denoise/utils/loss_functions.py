@@ -85,7 +85,7 @@ class Loss:
         h = ctypes.c_void_p()
         check(self.L.xsd_loss_create(ctypes.byref(cfg), ctypes.byref(h)))
         self.h = h
-        self.last_values = None   # device tensor [8]: total, l1, poisson, psnr, ssim, ms_ssim of the last call
+        self.last_values = None   # device tensor [12] of the last call: total, l1, poisson, psnr, ssim, ms_ssim, mse, min/max(target)
 
     def __del__(self):
         if getattr(self, "h", None) and self.h.value:
@@ -103,7 +103,7 @@ class Loss:
             B, H, W = preds.shape
         else:
             raise XsdError(f"expected [B,1,H,W] or [B,H,W], got {tuple(preds.shape)}")
-        out = torch.empty(8, device=preds.device, dtype=torch.float32)
+        out = torch.empty(12, device=preds.device, dtype=torch.float32)
         dy = torch.empty_like(preds) if want_grad else None
         check(self.L.xsd_loss_eval(self.h, preds.data_ptr(), target.data_ptr(), dy.data_ptr() if want_grad else None,
                                    out.data_ptr(), B, H, W, _stream_ptr(preds.device)))
