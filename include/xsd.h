@@ -44,7 +44,7 @@ typedef struct xsd_config {
     int32_t num_filters;   /* must be 32 (models.toml: filters = 32) */
     int32_t num_res_blocks;/* >= 1 (models.toml: residual_blocks = 4) */
     int32_t num_upsample;  /* SR only: (hr_res/lr_res)/2, 1 or 2 */
-    int32_t memory_efficient; /* accepted for API parity (rrdb_blocks.py:39-47 recompute policy); numerics identical */
+    int32_t memory_efficient; /* rrdb_blocks.py:39-47 recompute policy; numerics identical. Enforced by the host (chunked recompute), not here */
     int32_t reserved;
 } xsd_config;
 

@@ -247,3 +247,38 @@ def test_full_size_properties():
             assert float((g2 - 2.0 * g1).abs().max()) <= 1e-5 * float(g1.abs().max())
     assert float((ys["bf16x3"] - ys["fp32"]).abs().max()) < 1e-4
     assert float((ys["bf16x3_p16"] - ys["fp32"]).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("kind", ["dn", "sr"])
+def test_memory_efficient_recompute_matches_full_batch(kind, monkeypatch):
+    """memory_efficient=True (rrdb_blocks.py:39-47: same math, activations recomputed in backward) keeps no activations
+    between forward and backward and recomputes XSD_ME_CHUNK tiles at a time.  Outputs are bitwise those of the plain
+    path; gradients differ only by the summation order over chunks (5 tiles in chunks of 2 here)."""
+    from xmm_superres_denoise.models import GeneratorRRDB_DN, GeneratorRRDB_SR
+    from xmm_superres_denoise.parallel import DataParallelTrainer
+    monkeypatch.setenv("XSD_ME_CHUNK", "2")
+    torch.manual_seed(0)
+    mk = (lambda me: GeneratorRRDB_DN(1, 1, 32, 1, memory_efficient=me)) if kind == "dn" else \
+         (lambda me: GeneratorRRDB_SR(1, 1, 32, 1, num_upsample=1, memory_efficient=me))
+    plain, me = mk(False).cuda(), mk(True).cuda()
+    me.load_state_dict(plain.state_dict())
+    for m in (plain, me):
+        m.set_math("fp32")
+    s = 2 if kind == "sr" else 1
+    x = torch.rand(5, 1, 40, 48, device="cuda")
+    t = torch.rand(5, 1, 40 * s, 48 * s, device="cuda")
+    outs, grads, dxs = [], [], []
+    for m in (plain, me):
+        xi = x.clone().requires_grad_(True)
+        y = m(xi)
+        (y - t).abs().mean().backward()
+        outs.append(y.detach()); dxs.append(xi.grad.clone())
+        grads.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]))
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(dxs[0], dxs[1])                      # per-tile input gradients do not depend on the batching
+    assert (grads[0] - grads[1]).abs().max().item() <= 2e-6 * grads[0].abs().max().item()
+    # trainer path: identical update (up to that summation order) and both replicas keep training
+    ta, tb = DataParallelTrainer(plain, lr=1e-3), DataParallelTrainer(me, lr=1e-3)
+    la, lb = float(ta.train_step(x, t)), float(tb.train_step(x, t))
+    assert la == lb
+    assert (ta.grads - tb.grads).abs().max().item() <= 2e-6 * ta.grads.abs().max().item()

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import functools
 import math
+import os
 
 import torch
 from torch import nn
@@ -18,22 +19,74 @@ from xmm_superres_denoise.engine import Engine, XsdError
 from .rrdb_blocks import RRDB, make_layer
 
 
+def me_chunk() -> int:
+    """tiles per recompute chunk of the memory_efficient path (activations kept: 2.1 GB per 512 x 512 tile)"""
+    return max(1, int(os.environ.get("XSD_ME_CHUNK", "8")))
+
+
+def forward_chunked(eng, x, chunk):
+    """forward without keeping activations, `chunk` tiles at a time (outputs are bitwise independent of the batching)"""
+    return torch.cat([eng.forward(x[i:i + chunk].contiguous(), save_for_backward=False) for i in range(0, x.shape[0], chunk)])
+
+
+def backward_recompute(eng, x, dy, grads, need_dx, chunk, last_chunk_hook=None):
+    """memory_efficient backward (the reference's checkpointing of every dense-block layer, rrdb_blocks.py:17-19,39-47,
+    restated at batch granularity): re-run the forward of `chunk` tiles keeping activations, run their backward,
+    accumulate the flat parameter gradient.  Peak activation memory = chunk tiles instead of the batch.
+    last_chunk_hook(stage): called after each backward stage of the LAST chunk, when grads' range of that stage is final."""
+    B = x.shape[0]
+    dx = torch.empty_like(x) if need_dx else None
+    tmp = torch.empty_like(grads)
+    starts = list(range(0, B, chunk))
+    for i in starts:
+        last = i == starts[-1]
+        eng.forward(x[i:i + chunk].contiguous(), save_for_backward=True)
+        dyc = dy[i:i + chunk].contiguous()
+        dxc = torch.empty_like(x[i:i + chunk]) if need_dx else None
+        for st in range(eng.num_stages):
+            eng.backward_stage(st, dyc, tmp, dx=dxc)
+            if last:
+                off, cnt = eng.grad_range(st)
+                if i == 0:
+                    grads[off:off + cnt].copy_(tmp[off:off + cnt])
+                else:
+                    grads[off:off + cnt].add_(tmp[off:off + cnt])
+                if last_chunk_hook is not None:
+                    last_chunk_hook(st)
+        if not last:
+            if i == 0:
+                grads.copy_(tmp)
+            else:
+                grads.add_(tmp)
+        if need_dx:
+            dx[i:i + chunk].copy_(dxc)
+    return dx
+
+
 class _EngineFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, need, x, *params):
         eng = module._get_engine(x.device)
         eng.pack(module._flat)
-        y = eng.forward(x.contiguous(), save_for_backward=need)
         ctx.module = module
         ctx.need_dx = x.requires_grad
-        return y
+        ctx.recompute = bool(need and module.memory_efficient)
+        if ctx.recompute:
+            ctx.save_for_backward(x)
+            return forward_chunked(eng, x.contiguous(), me_chunk())
+        return eng.forward(x.contiguous(), save_for_backward=need)
 
     @staticmethod
     def backward(ctx, dy):
         m = ctx.module
         eng = m._engine
         grads = torch.empty_like(m._flat)
-        dx = eng.backward(dy.contiguous(), grads, need_dx=ctx.need_dx)
+        if ctx.recompute:
+            (x,) = ctx.saved_tensors
+            eng.pack(m._flat)
+            dx = backward_recompute(eng, x.contiguous(), dy.contiguous(), grads, ctx.need_dx, me_chunk())
+        else:
+            dx = eng.backward(dy.contiguous(), grads, need_dx=ctx.need_dx)
         outs, off = [], 0
         for p in m._plist:
             n = p.numel()

@@ -48,14 +48,26 @@ class DataParallelTrainer:
     def train_step(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         eng = self.engine
         eng.pack(self.flat)
-        y = eng.forward(x, save_for_backward=True)
+        recompute = bool(getattr(self.model, "memory_efficient", False))
+        if recompute:   # rrdb_blocks.py:39-47 policy at batch granularity: keep no activations, recompute per chunk
+            from xmm_superres_denoise.models.modules.generator_rrdb import backward_recompute, forward_chunked, me_chunk
+            y = forward_chunked(eng, x, me_chunk())
+        else:
+            y = eng.forward(x, save_for_backward=True)
         loss, dy = eng.l1_loss(y, target) if self.loss is None else self.loss.value_and_grad(y, target)
         works = []
-        for st in range(eng.num_stages):
-            eng.backward_stage(st, dy, self.grads)
+
+        def reduce_stage(st):
             if self.world > 1:
                 off, cnt = eng.grad_range(st)
                 works.append(dist.all_reduce(self.grads[off:off + cnt], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+        if recompute:
+            backward_recompute(eng, x, dy, self.grads, False, me_chunk(), reduce_stage)
+        else:
+            for st in range(eng.num_stages):
+                eng.backward_stage(st, dy, self.grads)
+                reduce_stage(st)
         for w in works:
             w.wait()
         self.step_count += 1
