@@ -13,7 +13,7 @@ from util_hip import nchw_to_planes, planes_to_nchw, ptr_array
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["fp32-small", "bf16x3-small", "fp32-big", "bf16x3-big", "bf16x3_p16-small", "bf16x3_p16-v2"])
+@pytest.fixture(scope="module", params=["fp32-small", "bf16x3-small", "fp32-big", "bf16x3-big", "bf16x3_p16-small", "bf16x3_p16-v2", "bf16x3_p16-v3"])
 def eng(request):
     import os
     from xmm_superres_denoise.engine import Engine

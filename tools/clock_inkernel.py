@@ -1,7 +1,7 @@
 import sys, os, ctypes, torch
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, ROOT+'/xmm-superres-denoise_amd', ROOT+'/tests/golden'): sys.path.insert(0,p)
-os.environ['XSD_P16']='v2'
+os.environ.setdefault('XSD_P16','v2')
 from xmm_superres_denoise.models import GeneratorRRDB_DN
 torch.manual_seed(0)
 m = GeneratorRRDB_DN(1,1,32,4).cuda().set_math('bf16x3_p16')

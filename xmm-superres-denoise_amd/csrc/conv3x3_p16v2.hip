@@ -23,7 +23,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int QW = 8;                        // waves
-constexpr int QT = QW * 64;                  // 512 threads
 constexpr int QTH = 2 * QW;                  // 16 tile rows
 constexpr int QHH = QTH + 2;                 // 18 halo rows
 constexpr int QPX = QHH * HALO_W;            // 612 halo pixels
@@ -35,7 +34,6 @@ constexpr int QW_BYTES = QW_CHUNKS * 1024;   // 18,432 = [9 taps][hi|lo][64 lane
 constexpr int Q_W0 = 3 * QIN_BYTES, Q_W1 = Q_W0 + QW_BYTES;  // three input half-tile buffers, two half-panel buffers
 constexpr int Q_BIAS = Q_W1 + QW_BYTES;      // 156,672
 constexpr int Q_LDS_BYTES = Q_BIAS + 5 * 32 * 4; // 157,312
-constexpr int QNG = (QIN_CHUNKS + QW - 1) / QW; // 5 in-tile chunks per wave
 
 
 constexpr int CW = 4;                         // compute waves (one per SIMD), 4 tile rows each
@@ -46,6 +44,12 @@ constexpr int NIN = (QIN_CHUNKS + LW - 1) / LW; // 10 input chunks per loader pe
 constexpr int NWL = (QW_CHUNKS + LW - 1) / LW;  // 5 weight chunks per loader per half-step
 constexpr int NSET = NIN + NWL;               // 15 x 16 B per lane per register set
 
+// ROWREUSE: the compute waves keep the half-panel's 18 weight fragments in registers and walk the 6 input rows of their
+// 4 output rows once, applying each input fragment to every output row that uses it (54 KB of LDS reads per wave and
+// half-step instead of 90 KB).
+// DBG: in-kernel clocks around the MFMA loop (tools/clock_inkernel.py); a template parameter because s_memtime shares
+// the LDS wait counter and would turn the counted waits of the production path into full drains.
+template <bool ROWREUSE, bool DBG>
 __global__ __launch_bounds__(TT, 2) void conv3x3_p16v2_kernel(const ConvParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -56,8 +60,6 @@ __global__ __launch_bounds__(TT, 2) void conv3x3_p16v2_kernel(const ConvParams P
     const int lw = wv - CW;
     const int h = lane >> 5;
     const int l31 = lane & 31;
-    constexpr bool MULTI_OUT = false;
-
     const int tilesY = (P.H + QTH - 1) / QTH;
     const int ntiles = P.B * tilesY * P.tilesX;
     const int nsteps = P.n_in;
@@ -181,8 +183,8 @@ __global__ __launch_bounds__(TT, 2) void conv3x3_p16v2_kernel(const ConvParams P
         }
     };
 
-    // ---- one half-step: 9 taps x 2 rows x (W_hi*X_lo + W_lo*X_hi + W_hi*X_hi), software pipelined one tap ahead
-    auto compute = [&](int ibuf, int wbuf) {
+    // ---- one half-step: 9 taps x 4 rows x (W_hi*X_lo + W_lo*X_hi + W_hi*X_hi)
+    auto compute_taps = [&](int ibuf, int wbuf) { // software pipelined one tap ahead; inputs re-read per tap
         const char* inb = smem + ibuf * QIN_BYTES;
         const char* wl = smem + (wbuf ? Q_W1 : Q_W0) + lane * 16;
         bf16x8 bfr[2][2];    // [set][part]
@@ -211,6 +213,52 @@ __global__ __launch_bounds__(TT, 2) void conv3x3_p16v2_kernel(const ConvParams P
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    auto compute_rows = [&](int ibuf, int wbuf) { // weights resident in registers, every input fragment read once
+        const char* inb = smem + ibuf * QIN_BYTES;
+        const char* wl = smem + (wbuf ? Q_W1 : Q_W0) + lane * 16;
+        bf16x8 w[9][2];      // [tap][hi|lo]
+        bf16x8 x[3][2];      // ring of input fragments, prefetched two steps ahead
+        // step order: the rows shared by three output rows first, so the short steps at the end run on prefetched data
+        constexpr int kRow[6] = {2, 3, 1, 4, 0, 5};
+        auto load_w = [&](int tap) {
+#pragma unroll
+            for (int part = 0; part < 2; ++part) w[tap][part] = *reinterpret_cast<const bf16x8*>(wl + (tap * 2 + part) * 1024);
+        };
+        auto load_x = [&](int step, int set) {
+            const int ri = kRow[step / 3], dx = step % 3;
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+                x[set][part] = *reinterpret_cast<const bf16x8*>(inb + abase[dx][part] + ri * QROWB);
+        };
+        // step 0 is (row 2, dx 0) and needs taps (dy,0).  At most 15 LDS reads can be outstanding behind a counted wait
+        // (lgkmcnt is 4 bits), so the rest of the panel is requested in the order of first use behind steps 0 and 1.
+        load_x(0, 0); load_w(0); load_w(3); load_w(6);
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(1, 1); load_w(1); load_w(4);
+#pragma unroll
+        for (int step = 0; step < 18; ++step) {
+            const int set = step % 3;
+            const int ri = kRow[step / 3], dx = step % 3;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int r = ri - dy;
+                    if (r < 0 || r >= RPW) continue;
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[dy * 3 + dx][term == 1 ? 1 : 0], x[set][term == 0 ? 1 : 0],
+                                                                     acc[r], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (step == 0) { load_w(7); load_x(2, 2); load_w(2); }
+            if (step == 1) { load_w(5); load_w(8); }
+            if (step + 3 < 18) load_x(step + 3, set);
+        }
+    };
+    auto compute = [&](int ibuf, int wbuf) {
+        if (ROWREUSE) compute_rows(ibuf, wbuf);
+        else compute_taps(ibuf, wbuf);
     };
 
     // ---- epilogue over P16 planes
@@ -282,31 +330,31 @@ __global__ __launch_bounds__(TT, 2) void conv3x3_p16v2_kernel(const ConvParams P
     };
 
 
-    TileXY cur = tile_of(0);
-    int s = 0, k = 0, ib = 0;
+    // Nested tile / step / half loops (not one flat half-step loop): the accumulators then live in fixed registers across a
+    // whole tile instead of being copied through the loop-carried merge every half-step.  One barrier per half-step, in
+    // lock step with the loader role.
+    int ib = 0, u = 0;
     half_barrier(); // half-step 0 published
-    // diagnostic (P.dbg != null): shader cycles and 100 MHz wall ticks spent inside the MFMA loop / the whole kernel
     unsigned long long cyc_mfma = 0, wall_mfma = 0;
-    const unsigned long long cyc0 = P.dbg ? __builtin_readcyclecounter() : 0, wall0 = P.dbg ? wall_clock64() : 0;
+    const unsigned long long cyc0 = DBG ? __builtin_readcyclecounter() : 0, wall0 = DBG ? wall_clock64() : 0;
 #pragma unroll 1
-    for (int u = 0; u < nhalf; ++u) {
-        const int s2 = u & 1;
-        const bool more = (u + 1 < nhalf);
-        if (s2 == 0 && s == 0) init_acc(0);
-        if (P.dbg) {
-            const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
-            if (!(P.ablate & 8)) compute(ib, s2);
-            cyc_mfma += __builtin_readcyclecounter() - c0; wall_mfma += wall_clock64() - w0;
-        } else if (!(P.ablate & 8)) compute(ib, s2);
-        if (s2 == 1 && s == nsteps - 1) epilogue(0, cur);
-        if (more) half_barrier();
-        ib = ib == 2 ? 0 : ib + 1;
-        if (s2) {
-            if (s + 1 == nsteps) { s = 0; if (more) cur = tile_of(++k); }
-            else ++s;
+    for (int k = 0; k < my_tiles; ++k) {
+        const TileXY cur = tile_of(k);
+        init_acc(0);
+#pragma unroll 1
+        for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const unsigned long long c0 = DBG ? __builtin_readcyclecounter() : 0, w0 = DBG ? wall_clock64() : 0;
+                if (!(P.ablate & 8)) compute(ib, s2);
+                if (DBG) { cyc_mfma += __builtin_readcyclecounter() - c0; wall_mfma += wall_clock64() - w0; }
+                if (s2 == 1 && s == nsteps - 1) epilogue(0, cur);
+                if (++u < nhalf) half_barrier();
+                ib = ib == 2 ? 0 : ib + 1;
+            }
         }
     }
-    if (P.dbg && tid == 0) {
+    if (DBG && P.dbg && tid == 0) {
         atomicAdd(&P.dbg[0], cyc_mfma); atomicAdd(&P.dbg[1], wall_mfma);
         atomicAdd(&P.dbg[2], (unsigned long long)(__builtin_readcyclecounter() - cyc0));
         atomicAdd(&P.dbg[3], (unsigned long long)(wall_clock64() - wall0));
@@ -316,14 +364,20 @@ __global__ __launch_bounds__(TT, 2) void conv3x3_p16v2_kernel(const ConvParams P
 
 } // namespace v2
 
-hipError_t launch_conv3x3_p16v2(const ConvParams& p, hipStream_t stream)
+hipError_t launch_conv3x3_p16v2(const ConvParams& p, int rowreuse, hipStream_t stream)
 {
     static bool done = false;
     static int ncu = 256;
+    typedef void (*kern_t)(const ConvParams);
+    static const kern_t kerns[2][2] = {{v2::conv3x3_p16v2_kernel<false, false>, v2::conv3x3_p16v2_kernel<false, true>},
+                                       {v2::conv3x3_p16v2_kernel<true, false>, v2::conv3x3_p16v2_kernel<true, true>}};
     if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v2::conv3x3_p16v2_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, v2::Q_LDS_BYTES);
-        if (e != hipSuccess) return e;
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[a][b]),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, v2::Q_LDS_BYTES);
+                if (e != hipSuccess) return e;
+            }
         hipDeviceProp_t prop;
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
@@ -332,7 +386,7 @@ hipError_t launch_conv3x3_p16v2(const ConvParams& p, hipStream_t stream)
     const int tilesY = (p.H + v2::QTH - 1) / v2::QTH;
     const int ntiles = p.B * p.tilesX * tilesY;
     if (ntiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(v2::conv3x3_p16v2_kernel, dim3(ntiles < ncu ? ntiles : ncu), dim3(v2::TT), v2::Q_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(kerns[rowreuse ? 1 : 0][p.dbg ? 1 : 0], dim3(ntiles < ncu ? ntiles : ncu), dim3(v2::TT), v2::Q_LDS_BYTES, stream, p);
     return hipGetLastError();
 }
 

@@ -41,7 +41,7 @@ hipError_t launch_pack_weights_p16(const float* params, const PackDesc* descs_de
                                    unsigned short* bwd, hipStream_t s);
 hipError_t launch_plane_convert(const float* in, float* out, long long npix, int to_p16, hipStream_t s);
 hipError_t launch_conv3x3_p16(const ConvParams& p, hipStream_t stream);
-hipError_t launch_conv3x3_p16v2(const ConvParams& p, hipStream_t stream);
+hipError_t launch_conv3x3_p16v2(const ConvParams& p, int rowreuse, hipStream_t stream);
 hipError_t launch_wgrad_p16(const WgradParams& p, hipStream_t stream);
 hipError_t launch_pack_edge(const float* w_first, const float* w_last, float* ff, float* fb, float* lf, float* lb,
                             hipStream_t s);

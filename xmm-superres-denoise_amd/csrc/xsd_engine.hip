@@ -76,7 +76,7 @@ struct xsd_engine {
     float* pk_bwd = nullptr;
     unsigned short* pk_fwd_s = nullptr; // bf16x3 (hi|lo) panels, same byte size / offsets as pk_fwd / pk_bwd
     unsigned short* pk_bwd_s = nullptr;
-    int p16v2 = 0;             // math mode 2 K-loop convs: 0 = conv3x3_p16 (all waves DMA + MFMA), 1 = role-split conv3x3_p16v2
+    int p16v2 = 0;             // math mode 2 K-loop convs: 0 = conv3x3_p16 (all waves DMA + MFMA), 1 = role-split conv3x3_p16v2, 2 = role-split + row reuse
     int chunk = 0;             // images per dense-block sweep (0 = whole batch): keeps one block's planes in the 256 MB Infinity Cache
     int ablate = 0;            // diagnostic (env XSD_ABLATE)
     int big = 0;               // conv structure: 0 = 8x32 tile, 2 WG/CU; 1 = 16x32 tile, 1 WG/CU, LDS-DMA weight ring
@@ -251,7 +251,7 @@ struct Builder {
             p.dbg = eng->dbg;
             p.ablate = eng->ablate;
             p.zero = eng->zero_page;
-            return prof_launch(eng, 0, flop, bytes, s, [&]() { return eng->math == 2 ? ((eng->p16v2 && p.n_out == 1) ? launch_conv3x3_p16v2(p, s) : launch_conv3x3_p16(p, s)) : eng->big ? launch_conv3x3_big(p, eng->math, s) : launch_conv3x3_mfma(p, eng->math, s); });
+            return prof_launch(eng, 0, flop, bytes, s, [&]() { return eng->math == 2 ? ((eng->p16v2 && p.n_out == 1) ? launch_conv3x3_p16v2(p, eng->p16v2 == 2, s) : launch_conv3x3_p16(p, s)) : eng->big ? launch_conv3x3_big(p, eng->math, s) : launch_conv3x3_mfma(p, eng->math, s); });
         };
     }
     // wgrad + fixed-order reduce into the flat gradient vector
@@ -558,7 +558,7 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     e->cfg = *cfg;
     if (const char* m = getenv("XSD_ABLATE")) e->ablate = atoi(m);
     if (const char* m = getenv("XSD_CHUNK")) e->chunk = atoi(m);
-    if (const char* m = getenv("XSD_P16")) e->p16v2 = strcmp(m, "v2") == 0 ? 1 : 0;
+    if (const char* m = getenv("XSD_P16")) e->p16v2 = strcmp(m, "v3") == 0 ? 2 : strcmp(m, "v2") == 0 ? 1 : 0;
     if (const char* m = getenv("XSD_CONV")) e->big = strcmp(m, "big") == 0 ? 1 : 0;
     if (const char* m = getenv("XSD_MATH")) e->math = (strcmp(m, "bf16x3_p16") == 0 || strcmp(m, "2") == 0) ? 2 : (strcmp(m, "bf16x3") == 0 || strcmp(m, "1") == 0) ? 1 : 0;
     const int blocks = cfg->num_res_blocks, nup = cfg->kind == XSD_KIND_SR ? cfg->num_upsample : 0;
@@ -889,7 +889,7 @@ static hipError_t run_conv(xsd_engine* e, ConvParams& p, hipStream_t s)
 {
     p.zero = e->zero_page;
     for (int i = 0; i < (p.n_out > 1 ? p.n_out : p.n_in); ++i) p.wstep[i] = p.wpanel + (long long)i * PANEL_FLOATS;
-    if (e->math == 2) return (e->p16v2 && p.n_out == 1) ? launch_conv3x3_p16v2(p, s) : launch_conv3x3_p16(p, s);
+    if (e->math == 2) return (e->p16v2 && p.n_out == 1) ? launch_conv3x3_p16v2(p, e->p16v2 == 2, s) : launch_conv3x3_p16(p, s);
     return e->big ? launch_conv3x3_big(p, e->math, s) : launch_conv3x3_mfma(p, e->math, s);
 }
 
