@@ -266,6 +266,14 @@ def main():
                 roof["wgrad_kernel"] = {"achieved_TFLOPs": w["flop"] / wsec / 1e12, "achieved_GBps": w["bytes"] / wsec / 1e9,
                                         "launches": w["launches"], "avg_launch_ms": w["ms"] / w["launches"],
                                         "traffic": pmc_traffic(args.math, B, "wgrad") if (train and kind == "dn" and world == 1) else None}
+            # whole-step algorithmic bytes / flops per tile (fp32 counting rule) x tiles/s against the peaks
+            step_bytes = {("dn", True): 117020.0, ("dn", False): 33420.0, ("sr", True): 124224.0, ("sr", False): 35476.0}[(kind, train)] * TILE * TILE
+            step_flop = {("dn", True): 2.62e12, ("dn", False): 8.749e11, ("sr", True): 2.74e12, ("sr", False): 9.140e11}[(kind, train)]
+            per_gpu = tiles / dt / world
+            roof["whole_step"] = {"algorithmic_GBps": step_bytes * per_gpu / 1e9, "hbm_frac": step_bytes * per_gpu / 1e9 / HBM_PEAK_GBPS,
+                                  "algorithmic_TFLOPs": step_flop * per_gpu / 1e12,
+                                  "fp32_mfma_frac": step_flop * per_gpu / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                  "note": "per GPU; SURVEY.md 8(d) bytes/flops per tile x tiles/s"}
             out["roofline"] = roof
         if exact is not None:
             out["exact_fp32"] = exact
