@@ -214,6 +214,7 @@ __global__ __launch_bounds__(TT, 2) void conv3x3_p16v2_kernel(const ConvParams P
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    const bool skip_term = (P.ablate & 16) != 0; // diagnostic: drop the W_lo * X_hi products (wrong results, 2/3 of the MFMAs)
     auto compute_rows = [&](int ibuf, int wbuf) { // weights resident in registers, every input fragment read once
         const char* inb = smem + ibuf * QIN_BYTES;
         const char* wl = smem + (wbuf ? Q_W1 : Q_W0) + lane * 16;
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(TT, 2) void conv3x3_p16v2_kernel(const ConvParams P
                 for (int dy = 0; dy < 3; ++dy) {
                     const int r = ri - dy;
                     if (r < 0 || r >= RPW) continue;
+                    if (term == 1 && skip_term) continue;
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[dy * 3 + dx][term == 1 ? 1 : 0], x[set][term == 0 ? 1 : 0],
                                                                      acc[r], 0, 0, 0);
                 }
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(TT, 2) void conv3x3_p16v2_kernel(const ConvParams P
             for (int s2 = 0; s2 < 2; ++s2) {
                 const unsigned long long c0 = DBG ? __builtin_readcyclecounter() : 0, w0 = DBG ? wall_clock64() : 0;
                 if (!(P.ablate & 8)) compute(ib, s2);
+                else if (P.ablate & 32) { __builtin_amdgcn_s_sleep(32); __builtin_amdgcn_s_sleep(32); } // ~4096 idle cycles instead of the MFMA loop
                 if (DBG) { cyc_mfma += __builtin_readcyclecounter() - c0; wall_mfma += wall_clock64() - w0; }
                 if (s2 == 1 && s == nsteps - 1) epilogue(0, cur);
                 if (++u < nhalf) half_barrier();
