@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--input-pipeline", action="store_true",
                     help="configs[4]: each step starts from int32 count tiles (411x403, Poisson, seed 2) and runs the fused "
                          "detector-mask * pad * sqrt-normalize kernel on the GPU instead of reusing resident float tiles")
+    ap.add_argument("--loss", default="l1", choices=["l1", "paper"],
+                    help="l1 = BASELINE configs[2]; paper = the reference's shipped default 0.5 psnr + 0.5 ms_ssim with the "
+                         "'linear' scaling table (res/configs/loss_functions.toml), reported separately (SURVEY 8d config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the short exact-fp32 comparison run")
@@ -155,7 +158,11 @@ def main():
         tgt = torch.rand((B * world, 1, TILE * scale, TILE * scale), generator=gt)[rank * B:(rank + 1) * B].contiguous().to(dev)
 
     model.set_math(args.math)
-    trainer = DataParallelTrainer(model, lr=1e-4, betas=(0.9, 0.999))
+    loss_fn = None
+    if args.loss == "paper":
+        from xmm_superres_denoise.utils import create_loss, load_loss_config
+        loss_fn = create_loss(*load_loss_config("linear"))
+    trainer = DataParallelTrainer(model, lr=1e-4, betas=(0.9, 0.999), loss=loss_fn)
     eng = trainer.engine
 
     counts = mask = None
@@ -232,8 +239,8 @@ def main():
             "value": tiles / dt, "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
-            "config": {"workload": {"dn_train": "XMM-DeNoise train step (L1 + Adam), fwd+bwd HIP kernels",
-                                    "sr_train": "XMM-SuperRes 2x train step (L1 + Adam)",
+            "config": {"workload": {"dn_train": "XMM-DeNoise train step (%s + Adam), fwd+bwd HIP kernels" % ("L1" if args.loss == "l1" else "0.5 PSNR + 0.5 MS-SSIM"),
+                                    "sr_train": "XMM-SuperRes 2x train step (%s + Adam)" % ("L1" if args.loss == "l1" else "0.5 PSNR + 0.5 MS-SSIM"),
                                     "dn_fwd": "XMM-DeNoise forward", "sr_fwd": "XMM-SuperRes 2x generator forward"}[args.workload],
                        "tile": f"1x{TILE}x{TILE}", "per_gpu_batch": B, "global_batch": B * world,
                        "net": "RRDB nf=32 x 4 blocks", "math": args.math, "parallelism": f"dp{world}"},
