@@ -62,14 +62,15 @@ def test_forward_no_grad_matches_train_forward_and_reuses_planes():
 
 
 @pytest.mark.parametrize("math", MATHS)
-@pytest.mark.parametrize("kind,shape", [("dn", (3, 1, 41, 67)), ("sr", (2, 1, 33, 35))])
-def test_fresh_inputs_vs_oracle(kind, shape, math):
-    state = gc.make_state(kind, 32, 2, 900, num_upsample=1, last_bias=0.3 if kind == "sr" else None)
+@pytest.mark.parametrize("kind,shape,nup", [("dn", (3, 1, 41, 67), 1), ("sr", (2, 1, 33, 35), 1), ("sr", (2, 1, 19, 22), 2)])
+def test_fresh_inputs_vs_oracle(kind, shape, nup, math):
+    """nup = 2 is the class default of GeneratorRRDB_SR (generator_rrdb.py:79): two conv + PixelShuffle stages, 4x output"""
+    state = gc.make_state(kind, 32, 2, 900, num_upsample=nup, last_bias=0.3 if kind == "sr" else None)
     x = gc.make_input(shape, 901)
-    s = 2 if kind == "sr" else 1
+    s = 2 ** nup if kind == "sr" else 1
     t = gc.make_input((shape[0], 1, shape[2] * s, shape[3] * s), 902)
-    yo, lo, dxo, go = oracle.l1_train(kind, 32, 2, oracle.flatten_state(state), x, t, num_upsample=1)
-    m = build_module(kind, 2, 1, state).set_math(math)
+    yo, lo, dxo, go = oracle.l1_train(kind, 32, 2, oracle.flatten_state(state), x, t, num_upsample=nup)
+    m = build_module(kind, 2, nup, state).set_math(math)
     eng = m._get_engine(torch.device("cuda", 0))
     eng.pack(m.flat_parameters())
     xd = torch.from_numpy(x).cuda()
@@ -81,7 +82,7 @@ def test_fresh_inputs_vs_oracle(kind, shape, math):
     assert abs(loss.item() - lo) < 1e-5
     assert_grad_close(dx.cpu().numpy().reshape(-1, dxo.shape[-1]), dxo.reshape(-1, dxo.shape[-1]), "dx", tight=DX_TIGHT[math], loose=5e-2, max_flip_frac=0.3)
     g = grads.cpu().numpy()
-    shapes = gc.rrdb_param_shapes(kind, 32, 2, num_upsample=1)
+    shapes = gc.rrdb_param_shapes(kind, 32, 2, num_upsample=nup)
     off = 0
     for n, shp in shapes.items():
         k = int(np.prod(shp))
