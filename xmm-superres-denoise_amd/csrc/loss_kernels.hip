@@ -145,11 +145,14 @@ __global__ __launch_bounds__(NT) void ssim_kernel(const SsimParams P)
         st[r][c] = in ? tb[(long long)y * P.W + x] : 0.f;
     }
     __syncthreads();
+    // Variances and the covariance are shift invariant: the moments are taken about the tile's centre pixel (cp, ct), which
+    // removes the E[x^2] - mu^2 cancellation on nearly flat images (the coarse MS-SSIM scales); the means get it added back.
+    const float cp = sp[ext / 2][ext / 2], ct = st[ext / 2][ext / 2];
     for (int i = threadIdx.x; i < ext * TS; i += NT) {
         const int r = i / TS, c = i - r * TS;
         float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
         for (int k = 0; k <= R2; ++k) {
-            const float g = P.taps.g[k], x = sp[r][c + k], y = st[r][c + k];
+            const float g = P.taps.g[k], x = sp[r][c + k] - cp, y = st[r][c + k] - ct;
             a0 += g * x; a1 += g * y; a2 += g * (x * x); a3 += g * (y * y); a4 += g * (x * y);
         }
         hz[0][r][c] = a0; hz[1][r][c] = a1; hz[2][r][c] = a2; hz[3][r][c] = a3; hz[4][r][c] = a4;
@@ -170,9 +173,10 @@ __global__ __launch_bounds__(NT) void ssim_kernel(const SsimParams P)
         }
         const int oy = oy0 + y, ox = ox0 + c;
         if (oy >= P.Hv || ox >= P.Wv) continue;
-        const float vp_raw = epp - mp * mp, vt_raw = ett - mt * mt;
+        const float vp_raw = epp - mp * mp, vt_raw = ett - mt * mt;   // moments about (cp, ct)
         const float vp = fmaxf(vp_raw, 0.f), vt = fmaxf(vt_raw, 0.f);
         const float cov = ept - mp * mt;
+        mp += cp; mt += ct;                                           // the taps sum to 1
         const float U = 2.f * cov + c2, L = vp + vt + c2;
         const float A = 2.f * mp * mt + c1, Bq = mp * mp + mt * mt + c1;
         const float cs = U / L, lum = A / Bq;
@@ -191,8 +195,11 @@ __global__ __launch_bounds__(NT) void ssim_kernel(const SsimParams P)
             P.maps[o] = d_mp;
             P.maps[plane + o] = d_vp;
             P.maps[2 * plane + o] = d_cov;
-            acc0 += (double)(dA + dB);
-            acc1 += (double)(dU + dL);
+            // d/dc1 = dA + dB and d/dc2 = dU + dL, written without the cancellation of their nearly opposite terms:
+            // dA + dB = d_lum (Bq - A) / Bq^2 with Bq - A = (mu_p - mu_t)^2;  dU + dL = d_cs (L - U) / L^2
+            const float dm = mp - mt;
+            acc0 += (double)(d_lum * (dm * dm) / (Bq * Bq));
+            acc1 += (double)(d_cs * (vp + vt - 2.f * cov) / (L * L));
         }
     }
     acc0 = block_sum(acc0, red);
