@@ -16,38 +16,40 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams P)
 {
-    __shared__ float wl[9 * 32 + 32];
-    for (int i = threadIdx.x; i < 9 * 32; i += 256) wl[i] = P.w[i];
-    if (threadIdx.x < 32) wl[288 + threadIdx.x] = P.bias ? P.bias[threadIdx.x] : 0.f;
-    __syncthreads();
-    const long long npix = (long long)P.B * P.H * P.W;
-    const long long total = npix * 8;
-    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
-        const long long pix = g >> 3;
-        const int q = (int)(g & 7);
-        const int x = (int)(pix % P.W);
-        const long long r = pix / P.W;
-        const int y = (int)(r % P.H);
-        const float* sb = P.s + (r - y) * P.W; // start of image b
-        f32x4 v = *reinterpret_cast<const f32x4*>(&wl[288 + q * 4]);
+    // One image row per block iteration: the three rows of s around it are staged zero-padded in LDS, the thread's 9 x 4
+    // weights live in registers, and the row is swept two pixels per thread at a time (no per-pixel division).
+    __shared__ float srow[3][EDGE_MAX_W + 2];
+    const int q = threadIdx.x & 7, px0 = threadIdx.x >> 3;
+    const int ppos = 16 * (q & 1) + 4 * (q >> 1); // P16 position of channel 4q (p16.h)
+    f32x4 w4[9];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-            if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
-                const float sv = sb[(long long)yy * P.W + xx];
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wl[tap * 32 + q * 4]);
-                v += sv * w4;
+    for (int tap = 0; tap < 9; ++tap) w4[tap] = *reinterpret_cast<const f32x4*>(P.w + tap * 32 + q * 4);
+    const f32x4 b4 = P.bias ? *reinterpret_cast<const f32x4*>(P.bias + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nrows = P.B * P.H;
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int y = row % P.H;
+        const float* sb = P.s + (long long)(row - y) * P.W;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * (P.W + 2); i += 256) {
+            const int k = i / (P.W + 2), xx = i - k * (P.W + 2) - 1, yy = y + k - 1;
+            srow[k][xx + 1] = (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) ? sb[(long long)yy * P.W + xx] : 0.f;
+        }
+        __syncthreads();
+        const long long rbase = (long long)row * P.W * 32;
+        for (int x = px0; x < P.W; x += 32) {
+            f32x4 v = b4;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) v += srow[tap / 3][x + tap % 3] * w4[tap];
+            const long long o = rbase + (long long)x * 32;
+            if (P.mask) {
+                const f32x4 m = P.p16 ? p16_load4(reinterpret_cast<const char*>(P.mask + o), ppos)
+                                      : *reinterpret_cast<const f32x4*>(P.mask + o + q * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : v[i] * P.mslope;
             }
+            if (P.p16) p16_store4(reinterpret_cast<char*>(P.out + o), ppos, v);
+            else *reinterpret_cast<f32x4*>(P.out + o + q * 4) = v;
         }
-        const int ppos = 16 * (q & 1) + 4 * (q >> 1); // P16 position of channel 4q (p16.h)
-        if (P.mask) {
-            const f32x4 m = P.p16 ? p16_load4(reinterpret_cast<const char*>(P.mask + pix * 32), ppos)
-                                  : *reinterpret_cast<const f32x4*>(P.mask + pix * 32 + q * 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : v[i] * P.mslope;
-        }
-        if (P.p16) p16_store4(reinterpret_cast<char*>(P.out + pix * 32), ppos, v);
-        else *reinterpret_cast<f32x4*>(P.out + pix * 32 + q * 4) = v;
     }
 }
 
@@ -58,43 +60,52 @@ __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeReduceParams P)
 {
-    __shared__ float wl[9 * 32];
-    for (int i = threadIdx.x; i < 9 * 32; i += 256) wl[i] = P.w[i];
-    __syncthreads();
-    const float bias = P.bias ? P.bias[0] : 0.f;
-    const long long npix = (long long)P.B * P.H * P.W;
-    const long long total = (npix * 8 + 255) / 256 * 256; // keep whole waves alive for the shuffles
-    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
-        const long long pix = g >> 3;
-        const int q = (int)(g & 7);
-        float acc = 0.f;
-        if (pix < npix) {
-            const int x = (int)(pix % P.W);
-            const long long r = pix / P.W;
-            const int y = (int)(r % P.H);
-            const float* fb = P.f + (r - y) * P.W * 32;
+    // Block = (image, 32-pixel column strip, band of EDGE_BAND rows).  Thread = (column, 4-channel quad) walking down
+    // the band with a three-row register window: every feature pixel is fetched 3 times (left / centre / right thread)
+    // instead of 9, and no per-pixel division is needed.
+    const int q = threadIdx.x & 7, px = threadIdx.x >> 3;
+    const int pos = 16 * (q & 1) + 4 * (q >> 1);
+    f32x4 w4[9];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-                if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
-                    const float* pxp = fb + ((long long)yy * P.W + xx) * 32;
-                    const f32x4 fv = P.p16 ? p16_load4(reinterpret_cast<const char*>(pxp), 16 * (q & 1) + 4 * (q >> 1))
-                                           : *reinterpret_cast<const f32x4*>(pxp + q * 4);
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wl[tap * 32 + q * 4]);
-                    acc += fv[0] * w4[0] + fv[1] * w4[1] + fv[2] * w4[2] + fv[3] * w4[3];
-                }
+    for (int tap = 0; tap < 9; ++tap) w4[tap] = *reinterpret_cast<const f32x4*>(P.w + tap * 32 + q * 4);
+    const float bias = P.bias ? P.bias[0] : 0.f;
+    const int stripsX = (P.W + 31) / 32, bandsY = (P.H + EDGE_BAND - 1) / EDGE_BAND;
+    const int nblk = P.B * stripsX * bandsY;
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int sx = blk % stripsX, by = (blk / stripsX) % bandsY, b = blk / (stripsX * bandsY);
+        const int x = sx * 32 + px, y0 = by * EDGE_BAND;
+        const float* fb = P.f + (long long)b * P.H * P.W * 32;
+        const long long ob = (long long)b * P.H * P.W;
+        auto load = [&](int yy, int xx) {
+            if (yy < 0 || yy >= P.H || xx < 0 || xx >= P.W) return f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* pxp = fb + ((long long)yy * P.W + xx) * 32;
+            return P.p16 ? p16_load4(reinterpret_cast<const char*>(pxp), pos) : *reinterpret_cast<const f32x4*>(pxp + q * 4);
+        };
+        f32x4 r0[3], r1[3], r2[3];   // rows y-1, y, y+1 at columns x-1, x, x+1
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { r0[d] = load(y0 - 1, x - 1 + d); r1[d] = load(y0, x - 1 + d); }
+        const int yend = y0 + EDGE_BAND < P.H ? y0 + EDGE_BAND : P.H;
+        for (int y = y0; y < yend; ++y) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) r2[d] = load(y + 1, x - 1 + d);
+            f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) a4 += r0[d] * w4[d] + r1[d] * w4[3 + d] + r2[d] * w4[6 + d];
+            float acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            acc += __shfl_xor(acc, 4);
+            if (q == 0 && x < P.W) {
+                const long long pix = ob + (long long)y * P.W + x;
+                float v = acc + bias;
+                if (P.skip) v += P.skip[pix];
+                if (P.addto) v += P.addto[pix];
+                if (P.pre) P.pre[pix] = v;
+                if (P.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+                P.y[pix] = v;
             }
-        }
-        acc += __shfl_xor(acc, 1);
-        acc += __shfl_xor(acc, 2);
-        acc += __shfl_xor(acc, 4);
-        if (q == 0 && pix < npix) {
-            float v = acc + bias;
-            if (P.skip) v += P.skip[pix];
-            if (P.addto) v += P.addto[pix];
-            if (P.pre) P.pre[pix] = v;
-            if (P.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
-            P.y[pix] = v;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { r0[d] = r1[d]; r1[d] = r2[d]; }
         }
     }
 }
@@ -107,28 +118,45 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeReduceParams
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void edge_wgrad_kernel(const EdgeWgradParams P)
 {
+    // One image row per block iteration: the three rows of s around it are staged (zero padded) in LDS, then 8 threads
+    // per pixel (4 channels each) sweep the row.  No per-pixel division, 2 pixels in flight per thread.
     __shared__ float red[256 * 4];
-    const long long npix = (long long)P.B * P.H * P.W;
-    const int q = threadIdx.x & 7;
+    __shared__ float srow[3][EDGE_MAX_W + 2];
+    const int q = threadIdx.x & 7, px0 = threadIdx.x >> 3;
+    const int pos = 16 * (q & 1) + 4 * (q >> 1);
     f32x4 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 bs = {0.f, 0.f, 0.f, 0.f};
     float ss = 0.f;
-    for (long long pix = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3; pix < npix; pix += (long long)gridDim.x * 32) {
-        const int x = (int)(pix % P.W);
-        const long long r = pix / P.W;
-        const int y = (int)(r % P.H);
-        const float* sb = P.s + (r - y) * P.W;
-        const f32x4 fv = P.p16 ? p16_load4(reinterpret_cast<const char*>(P.f + pix * 32), 16 * (q & 1) + 4 * (q >> 1))
-                               : *reinterpret_cast<const f32x4*>(P.f + pix * 32 + q * 4);
-        bs += fv;
-        if (q == 0) ss += sb[(long long)y * P.W + x];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-            if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) acc[tap] += fv * sb[(long long)yy * P.W + xx];
+    const int nrows = P.B * P.H;
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int y = row % P.H;
+        const float* sb = P.s + (long long)(row - y) * P.W;     // image base
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * (P.W + 2); i += 256) {
+            const int k = i / (P.W + 2), xx = i - k * (P.W + 2) - 1, yy = y + k - 1;
+            srow[k][xx + 1] = (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) ? sb[(long long)yy * P.W + xx] : 0.f;
         }
+        __syncthreads();
+        const float* frow = P.f + (long long)row * P.W * 32;
+        auto load = [&](int x) {
+            return P.p16 ? p16_load4(reinterpret_cast<const char*>(frow + (long long)x * 32), pos)
+                         : *reinterpret_cast<const f32x4*>(frow + (long long)x * 32 + q * 4);
+        };
+        auto use = [&](int x, const f32x4& fv) {
+            bs += fv;
+            if (q == 0) ss += srow[1][x + 1];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) acc[tap] += fv * srow[tap / 3][x + tap % 3];
+        };
+        int x = px0;
+        for (; x + 32 < P.W; x += 64) {
+            const f32x4 f0 = load(x), f1 = load(x + 32);
+            use(x, f0);
+            use(x + 32, f1);
+        }
+        if (x < P.W) use(x, load(x));
     }
     float* outp = P.partial + (long long)blockIdx.x * (9 * 32 + 32 + 1);
     // reduce over the 32 threads of the block that share q
@@ -514,14 +542,14 @@ static inline int grid_for(long long n, int threads, int cap = 2048)
 
 hipError_t launch_edge_expand(const EdgeExpandParams& p, hipStream_t s)
 {
-    const long long total = (long long)p.B * p.H * p.W * 8;
-    hipLaunchKernelGGL(edge_expand_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, p);
+    const long long rows = (long long)p.B * p.H;
+    hipLaunchKernelGGL(edge_expand_kernel, dim3((unsigned)(rows < 4096 ? rows : 4096)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 hipError_t launch_edge_reduce(const EdgeReduceParams& p, hipStream_t s)
 {
-    const long long total = (long long)p.B * p.H * p.W * 8;
-    hipLaunchKernelGGL(edge_reduce_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, p);
+    const long long nblk = (long long)p.B * ((p.W + 31) / 32) * ((p.H + EDGE_BAND - 1) / EDGE_BAND);
+    hipLaunchKernelGGL(edge_reduce_kernel, dim3((unsigned)(nblk < 8192 ? nblk : 8192)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 hipError_t launch_edge_wgrad(const EdgeWgradParams& p, int mode, float* dw, float* db, hipStream_t s)

@@ -23,6 +23,8 @@
 #include "../../include/xsd.h"
 #include "xsd_aux.h"
 #include "xsd_loss.h"
+
+static constexpr int EDGE_WGRAD_BLOCKS = 2048; // 8 workgroups of 256 threads per CU
 #include "xsd_kernels.h"
 
 using namespace xsd;
@@ -401,7 +403,7 @@ struct Builder {
             S.push_back([eng, pre, dpre, npx](hipStream_t s) { return launch_clamp_bwd(pre, eng->b_dy, dpre, npx, s); });
             { // conv_last weight grad
                 EdgeWgradParams p; memset(&p, 0, sizeof(p)); p.p16 = e->math == 2;
-                p.B = B; p.H = H << lo; p.W = W << lo; p.f = sr ? H1 : T; p.s = dpre; p.nblocks = 512;
+                p.B = B; p.H = H << lo; p.W = W << lo; p.f = sr ? H1 : T; p.s = dpre; p.nblocks = EDGE_WGRAD_BLOCKS;
                 const long long wo = e->last_w, bo = e->last_b;
                 S.push_back([eng, p, wo, bo](hipStream_t s) mutable {
                     p.partial = eng->edge_partial; return launch_edge_wgrad(p, 1, eng->b_grads + wo, eng->b_grads + bo, s);
@@ -501,7 +503,7 @@ struct Builder {
             std::vector<Launch>& S = e->bwd_stages[blocks + 1];
             float* dFea = dR; // when blocks == 0 this is d(rrdb out) and needs + dT; blocks >= 1 is enforced at create
             EdgeWgradParams p; memset(&p, 0, sizeof(p)); p.p16 = e->math == 2;
-            p.B = B; p.H = H; p.W = W; p.f = dFea; p.nblocks = 512;
+            p.B = B; p.H = H; p.W = W; p.f = dFea; p.nblocks = EDGE_WGRAD_BLOCKS;
             const long long wo = e->first_w, bo = e->first_b;
             S.push_back([eng, p, wo, bo](hipStream_t s) mutable {
                 p.s = eng->b_x; p.partial = eng->edge_partial; return launch_edge_wgrad(p, 0, eng->b_grads + wo, eng->b_grads + bo, s);
@@ -609,7 +611,7 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     CK(hipMemcpy(e->descs_dev, descs.data(), sizeof(PackDesc) * descs.size(), hipMemcpyHostToDevice));
     CK(hipMalloc((void**)&e->wg_partial, sizeof(float) * (size_t)e->nparts * 5 * PANEL_FLOATS));
     CK(hipMalloc((void**)&e->wg_bias_partial, sizeof(float) * (size_t)e->nparts * 4 * 32));
-    CK(hipMalloc((void**)&e->edge_partial, sizeof(float) * 512 * 321));
+    CK(hipMalloc((void**)&e->edge_partial, sizeof(float) * EDGE_WGRAD_BLOCKS * 321));
     CK(hipMalloc((void**)&e->loss_partial, sizeof(double) * 1024));
 #undef CK
     *out = e;
@@ -662,6 +664,7 @@ int xsd_forward(xsd_engine* e, const float* dev_x, float* dev_y, int B, int H, i
     if (!e->packed) return fail(XSD_ERR_STATE, "xsd_pack_weights must be called before xsd_forward");
     const int lo = e->cfg.kind == XSD_KIND_SR ? e->cfg.num_upsample : 0;
     if ((long long)(H << lo) * (W << lo) * 32 >= (1ll << 31)) return fail(XSD_ERR_ARG, "image too large for 32-bit in-image offsets");
+    if ((W << lo) > EDGE_MAX_W) return fail(XSD_ERR_ARG, "output rows wider than %d pixels are not supported", EDGE_MAX_W);
     int rc = ensure_plan(e, B, H, W, save_for_backward != 0);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;

@@ -118,6 +118,8 @@ struct EdgeReduceParams { // 32 -> 1 conv: pre[p] = bias + sum_tap sum_c f[p+tap
     const float* addto;  // y = value + addto[p] (used for dx = dgrad + skip-grad), may be null
     int p16;             // plane f is P16
 };
+constexpr int EDGE_BAND = 32;     // rows per workgroup of the 32 -> 1 edge conv
+constexpr int EDGE_MAX_W = 4096;  // widest image row the edge kernels stage in LDS
 struct EdgeWgradParams { // out[tap][c] = sum_p f[p][c] * s[p+tap]; bsum[c] = sum_p f[p][c]; ssum = sum_p s[p]
     int B, H, W;
     const float* f;
