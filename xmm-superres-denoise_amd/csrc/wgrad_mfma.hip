@@ -355,36 +355,40 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_bf16x3_kernel(const Wgrad
 }
 
 // Fixed-order combination of the per-workgroup partials into the OIHW gradient (state-dict layout).
-// Block = 1024 threads = 16 waves: wave w sums partials [w*P/16, (w+1)*P/16) of 64 consecutive elements (16 loads in
-// flight per lane), then the 16 wave sums are combined in fixed order through LDS: deterministic and ~20x shorter than a
-// serial 256-term chain per element.
+// Block = 1024 threads = 16 waves over 256 consecutive elements: wave w sums partials [w*P/16, (w+1)*P/16) with one
+// float4 per lane (1 KiB contiguous per wave-load, 16 loads in flight), then the 16 wave sums are combined in fixed
+// order through LDS: deterministic, and the same summation order for any launch geometry.
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReduceParams R)
 {
-    __shared__ double red[16][64];
-    const int total = R.n_g * R.n_in * 9 * 1024;
+    __shared__ double red[16][256];
+    const int total = R.n_g * R.n_in * 9 * 1024;        // multiple of 256
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + lane;
+    const int e4 = blockIdx.x * 256 + lane * 4;
     const long long stride = (long long)R.n_g * R.n_in * 9 * 1024;
     const int per = (R.nparts + 15) / 16;
     const int p0 = w * per, p1 = min(R.nparts, p0 + per);
-    double s = 0.0;
-    if (e < total) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (e4 < total) {
         int p = p0;
         for (; p + 8 <= p1; p += 8) {
-            float v[8];
+            f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = R.partial[(p + u) * stride + e];
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(R.partial + (p + u) * stride + e4);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += (double)v[u];
+            for (int u = 0; u < 8; ++u) { s0 += (double)v[u][0]; s1 += (double)v[u][1]; s2 += (double)v[u][2]; s3 += (double)v[u][3]; }
         }
-        for (; p < p1; ++p) s += (double)R.partial[p * stride + e];
+        for (; p < p1; ++p) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(R.partial + p * stride + e4);
+            s0 += (double)v[0]; s1 += (double)v[1]; s2 += (double)v[2]; s3 += (double)v[3];
+        }
     }
-    red[w][lane] = s;
+    red[w][lane * 4 + 0] = s0; red[w][lane * 4 + 1] = s1; red[w][lane * 4 + 2] = s2; red[w][lane * 4 + 3] = s3;
     __syncthreads();
-    if (w == 0 && e < total) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x < 256 && e < total) {
         double t = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][lane];
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
         int r = e;
         const int co = r & 31; r >>= 5;
         const int ci = r & 31; r >>= 5;
@@ -395,14 +399,36 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReducePar
         const int oc = R.shuffle ? (4 * cch + n) : (32 * n + cch);
         R.dw[((long long)oc * R.cin_total + (32 * j + ich)) * 9 + tap] = (float)(t * (double)R.scale);
     }
-    // bias: block 0, one wave per 64 (n, co) entries
-    if (blockIdx.x == 0 && threadIdx.x < R.n_g * 32) {
-        const int co = threadIdx.x & 31, n = threadIdx.x >> 5;
-        double t = 0.0;
-        for (int p = 0; p < R.nparts; ++p) t += (double)R.bias_partial[((long long)p * R.n_g + n) * 32 + co];
-        const int cch = R.p16 ? p16_ch(co) : co;
-        const int oc = R.shuffle ? (4 * cch + n) : (32 * n + cch);
-        R.db[oc] = (float)(t * (double)R.scale);
+    // bias: block 0; the same 16 x (P/16) fixed-order scheme (a serial 256-load chain here used to cost 60 us per launch)
+    if (blockIdx.x == 0) {
+        const int nb = R.n_g * 32; // <= 128 entries (n, co)
+        __syncthreads();
+        for (int base = 0; base < nb; base += 64) {
+            const int idx = base + lane;
+            double t = 0.0;
+            if (idx < nb) {
+                int p = p0;
+                for (; p + 8 <= p1; p += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = R.bias_partial[(long long)(p + u) * nb + idx];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t += (double)v[u];
+                }
+                for (; p < p1; ++p) t += (double)R.bias_partial[(long long)p * nb + idx];
+            }
+            if (idx < 256) red[w][idx] = t;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nb) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+            const int co = threadIdx.x & 31, n = threadIdx.x >> 5;
+            const int cch = R.p16 ? p16_ch(co) : co;
+            const int oc = R.shuffle ? (4 * cch + n) : (32 * n + cch);
+            R.db[oc] = (float)(t * (double)R.scale);
+        }
     }
 }
 
@@ -427,7 +453,7 @@ hipError_t launch_wgrad_mfma(const WgradParams& p, int split, hipStream_t stream
 hipError_t launch_wgrad_reduce(const WgradReduceParams& r, hipStream_t stream)
 {
     const int total = r.n_g * r.n_in * 9 * 1024;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(1024), 0, stream, r);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(1024), 0, stream, r);
     return hipGetLastError();
 }
 
