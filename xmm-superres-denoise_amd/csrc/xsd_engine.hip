@@ -275,7 +275,7 @@ struct Builder {
         const long long w_off = cw.w_off, b_off = cw.b_off;
         const double px = (double)wp.B * wp.H * wp.W;
         const double flop = 2.0 * 9 * 32 * 32 * wp.n_in * wp.n_g * px;
-        const double bytes = 128.0 * 2 * wp.n_in * wp.n_g * px;
+        const double bytes = 128.0 * (wp.n_in + wp.n_g) * px; // SURVEY 8(d) rule: every X plane and every G plane once (the kernel itself re-reads G once per X plane)
         ops.push_back([eng, wp, rp, w_off, b_off, flop, bytes](hipStream_t s) mutable {
             wp.partial = eng->wg_partial; wp.bias_partial = eng->wg_bias_partial;
             rp.partial = eng->wg_partial; rp.bias_partial = eng->wg_bias_partial;
