@@ -84,6 +84,17 @@ __global__ __launch_bounds__(TT, 2) void conv3x3_p16v2_kernel(const ConvParams P
 
     float* bias_lds = reinterpret_cast<float*>(smem + Q_BIAS);
     if (tid < 160) bias_lds[tid] = (P.bias && tid < 32) ? P.bias[tid] : 0.f;
+    if (P.ablate & 256) { // diagnostic: realistic operand bits in every LDS buffer (for MFMA-only runs: zeros draw less power)
+        unsigned int* w32 = reinterpret_cast<unsigned int*>(smem);
+        for (int i = tid; i < Q_BIAS / 4; i += TT) {
+            unsigned int x = (unsigned int)i * 2654435761u + blockIdx.x * 40503u;
+            x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+            // two bf16: sign | exponent 0x7E (0.5..1) or 0x76 for "lo" words | 7 mantissa bits
+            const unsigned int e = ((i >> 3) & 1) ? 0x3B00u : 0x3F00u;
+            w32[i] = ((x & 0x807Fu) | e) | ((((x >> 16) & 0x807Fu) | e) << 16);
+        }
+        __syncthreads();
+    }
 
     if (loader) {
         // ================================================================================================ loader role
@@ -324,6 +335,18 @@ __global__ __launch_bounds__(TT, 2) void conv3x3_p16v2_kernel(const ConvParams P
             const u32x4 h0 = {hw[0], hw[1], hw[2], hw[3]}, h1 = {hw[4], hw[5], hw[6], hw[7]};
             const u32x4 l0 = {lw[0], lw[1], lw[2], lw[3]}, l1 = {lw[4], lw[5], lw[6], lw[7]};
             char* px = reinterpret_cast<char*>(dst + od) + h * 32;
+            if (P.ablate & 64) { // diagnostic: everything but the global stores (keep the values alive)
+                asm volatile("" ::"v"(h0), "v"(h1), "v"(l0), "v"(l1));
+                continue;
+            }
+            if (P.ablate & 128) { // diagnostic: the same bytes of the same row, permuted so every store instruction is 1 KiB contiguous
+                char* rowb = reinterpret_cast<char*>(dst + (long long)y * o.rs + (long long)T.x0 * o.ps) + lane * 16;
+                *reinterpret_cast<u32x4*>(rowb) = h0;
+                *reinterpret_cast<u32x4*>(rowb + 1024) = h1;
+                *reinterpret_cast<u32x4*>(rowb + 2048) = l0;
+                *reinterpret_cast<u32x4*>(rowb + 3072) = l1;
+                continue;
+            }
             *reinterpret_cast<u32x4*>(px) = h0;
             *reinterpret_cast<u32x4*>(px + 16) = h1;
             *reinterpret_cast<u32x4*>(px + 64) = l0;
