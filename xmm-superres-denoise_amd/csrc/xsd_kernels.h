@@ -53,7 +53,10 @@ struct ConvParams {
     const float* wpanel; // [n_out][n_in] panels (one of the two is 1), PANEL_FLOATS each (host side; kernels read wstep)
     const float* wstep[5]; // weight panel of each step (K-loop step or output chunk)
     const float* bias;   // [n_out*32] or nullptr
-    int ablate;          // diagnostic ablation bits (0 in production): 1 skip input loads, 2 skip weight loads, 4 skip stores, 8 skip MFMA loop
+    int ablate;          // diagnostic ablation bits (0 in production; env XSD_ABLATE): 1 skip input loads, 2 skip weight loads,
+                         // 4 skip the epilogue, 8 skip the MFMA loop; role-split kernel only: 16 two of three products,
+                         // 32 idle sleep instead of the MFMA loop (with 8), 64 epilogue without its stores, 128 permuted
+                         // fully coalesced stores, 256 fill LDS with realistic operand bits
     int pad_;
     const void* zero;    // >= 64 B of zeros in HBM (math mode 2: DMA source for zero padding)
     unsigned long long* dbg; // diagnostic phase stamps (null in production): [grid][8] accumulated shader cycles
