@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams
 // input-gradient of conv_first).  8 lanes per pixel, each 4 channels x 9 taps, xor-shuffle reduction over the 8 lanes.
 // Algorithmic bytes/px: 128 read (+4 skip) + 4..8 written.
 // ---------------------------------------------------------------------------------------------------------------
+template <bool P16>
 __global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeReduceParams P)
 {
     // Block = (image, 32-pixel column strip, band of EDGE_BAND rows).  Thread = (column, 4-channel quad) walking down
@@ -76,10 +77,12 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeReduceParams
         const int x = sx * 32 + px, y0 = by * EDGE_BAND;
         const float* fb = P.f + (long long)b * P.H * P.W * 32;
         const long long ob = (long long)b * P.H * P.W;
-        auto load = [&](int yy, int xx) {
-            if (yy < 0 || yy >= P.H || xx < 0 || xx >= P.W) return f32x4{0.f, 0.f, 0.f, 0.f};
-            const float* pxp = fb + ((long long)yy * P.W + xx) * 32;
-            return P.p16 ? p16_load4(reinterpret_cast<const char*>(pxp), pos) : *reinterpret_cast<const f32x4*>(pxp + q * 4);
+        auto load = [&](int yy, int xx) { // branch-free: out-of-image taps read the image's first pixel and are zeroed
+            const bool ok = yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
+            const float* pxp = fb + (ok ? ((long long)yy * P.W + xx) * 32 : 0);
+            const f32x4 v = P16 ? p16_load4(reinterpret_cast<const char*>(pxp), pos) : *reinterpret_cast<const f32x4*>(pxp + q * 4);
+            const float m = ok ? 1.f : 0.f;
+            return v * m;
         };
         f32x4 r0[3], r1[3], r2[3];   // rows y-1, y, y+1 at columns x-1, x, x+1
 #pragma unroll
@@ -88,6 +91,11 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeReduceParams
         for (int y = y0; y < yend; ++y) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) r2[d] = load(y + 1, x - 1 + d);
+            // the scalar side inputs of this output pixel travel with the feature loads (one memory latency per row, not two)
+            const bool owner = q == 0 && x < P.W;
+            const long long pix = ob + (long long)y * P.W + x;
+            const float sk = (owner && P.skip) ? P.skip[pix] : 0.f;
+            const float ad = (owner && P.addto) ? P.addto[pix] : 0.f;
             f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int d = 0; d < 3; ++d) a4 += r0[d] * w4[d] + r1[d] * w4[3 + d] + r2[d] * w4[6 + d];
@@ -95,11 +103,10 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeReduceParams
             acc += __shfl_xor(acc, 1);
             acc += __shfl_xor(acc, 2);
             acc += __shfl_xor(acc, 4);
-            if (q == 0 && x < P.W) {
-                const long long pix = ob + (long long)y * P.W + x;
+            if (owner) {
                 float v = acc + bias;
-                if (P.skip) v += P.skip[pix];
-                if (P.addto) v += P.addto[pix];
+                if (P.skip) v += sk;
+                if (P.addto) v += ad;
                 if (P.pre) P.pre[pix] = v;
                 if (P.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
                 P.y[pix] = v;
@@ -116,6 +123,7 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeReduceParams
 //  conv_last : f = trunk features, s = dy -> dW[0][c][tap] = out[8-tap][c], db[0] = ssum
 // Deterministic two-stage reduction (per-block partials, then edge_wgrad_final_kernel).
 // ---------------------------------------------------------------------------------------------------------------
+template <bool P16>
 __global__ __launch_bounds__(256) void edge_wgrad_kernel(const EdgeWgradParams P)
 {
     // One image row per block iteration: the three rows of s around it are staged (zero padded) in LDS, then 8 threads
@@ -141,8 +149,8 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const EdgeWgradParams P
         __syncthreads();
         const float* frow = P.f + (long long)row * P.W * 32;
         auto load = [&](int x) {
-            return P.p16 ? p16_load4(reinterpret_cast<const char*>(frow + (long long)x * 32), pos)
-                         : *reinterpret_cast<const f32x4*>(frow + (long long)x * 32 + q * 4);
+            return P16 ? p16_load4(reinterpret_cast<const char*>(frow + (long long)x * 32), pos)
+                       : *reinterpret_cast<const f32x4*>(frow + (long long)x * 32 + q * 4);
         };
         auto use = [&](int x, const f32x4& fv) {
             bs += fv;
@@ -151,12 +159,14 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const EdgeWgradParams P
             for (int tap = 0; tap < 9; ++tap) acc[tap] += fv * srow[tap / 3][x + tap % 3];
         };
         int x = px0;
-        for (; x + 32 < P.W; x += 64) {
-            const f32x4 f0 = load(x), f1 = load(x + 32);
+        for (; x + 96 < P.W; x += 128) {
+            const f32x4 f0 = load(x), f1 = load(x + 32), f2 = load(x + 64), f3 = load(x + 96);
             use(x, f0);
             use(x + 32, f1);
+            use(x + 64, f2);
+            use(x + 96, f3);
         }
-        if (x < P.W) use(x, load(x));
+        for (; x < P.W; x += 32) use(x, load(x));
     }
     float* outp = P.partial + (long long)blockIdx.x * (9 * 32 + 32 + 1);
     // reduce over the 32 threads of the block that share q
@@ -549,12 +559,14 @@ hipError_t launch_edge_expand(const EdgeExpandParams& p, hipStream_t s)
 hipError_t launch_edge_reduce(const EdgeReduceParams& p, hipStream_t s)
 {
     const long long nblk = (long long)p.B * ((p.W + 31) / 32) * ((p.H + EDGE_BAND - 1) / EDGE_BAND);
-    hipLaunchKernelGGL(edge_reduce_kernel, dim3((unsigned)(nblk < 8192 ? nblk : 8192)), dim3(256), 0, s, p);
+    if (p.p16) hipLaunchKernelGGL(edge_reduce_kernel<true>, dim3((unsigned)(nblk < 8192 ? nblk : 8192)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(edge_reduce_kernel<false>, dim3((unsigned)(nblk < 8192 ? nblk : 8192)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 hipError_t launch_edge_wgrad(const EdgeWgradParams& p, int mode, float* dw, float* db, hipStream_t s)
 {
-    hipLaunchKernelGGL(edge_wgrad_kernel, dim3(p.nblocks), dim3(256), 0, s, p);
+    if (p.p16) hipLaunchKernelGGL(edge_wgrad_kernel<true>, dim3(p.nblocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(edge_wgrad_kernel<false>, dim3(p.nblocks), dim3(256), 0, s, p);
     hipLaunchKernelGGL(edge_wgrad_final_kernel, dim3(321), dim3(64), 0, s, p.partial, p.nblocks, mode, dw, db);
     return hipGetLastError();
 }
