@@ -6,7 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))          # .../xmm-superres-denoise_amd
-LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libxsd_hip.so")
+LIB_PATH = os.environ.get("XSD_LIB") or os.path.join(_PKG_ROOT, "lib", "libxsd_hip.so")   # XSD_LIB: A/B builds
 CSRC_DIR = os.path.join(_PKG_ROOT, "csrc")
 
 _lib = None
