@@ -177,3 +177,44 @@ def test_validation_metric_collection_epoch_accumulation():
     mi = get_in_metrics(ds, scalers[:1], "val")
     mi.update(torch.from_numpy(p1).cuda()[:, None], torch.from_numpy(t1).cuda()[:, None])
     assert "val/linear/in/psnr" in mi.compute()
+
+
+def test_model_validation_epoch_matches_oracle():
+    """Model.validation_step / on_validation_epoch_end (models/model.py:56-60,87-150): epoch-level loss of the composed
+    metric and the metric collections (input metrics on the nearest-upsampled LR image) over two SR batches."""
+    from xmm_superres_denoise.config.config import model_cfg
+    from xmm_superres_denoise.metrics import get_in_metrics, get_metrics
+    from xmm_superres_denoise.models import Model
+    from xmm_superres_denoise.transforms import Normalize
+    from xmm_superres_denoise.utils import create_loss, load_loss_config
+    torch.manual_seed(1)
+    sc, cfg = load_loss_config("linear")
+    ds = Normalize(0.0022336, 0.0005584, "linear")
+    scalers = [Normalize(0.0022336, 0.0005584, "linear")]
+    model = Model(model_cfg("esr_gen", batch_size=2, residual_blocks=1), (160, 160), (320, 320), create_loss(sc, cfg),
+                  get_metrics(ds, scalers, "val"), None, get_in_metrics(ds, scalers, "val"), None)
+    model.configure_model()
+    model.cuda()
+    batches = []
+    for seed in (41, 42):
+        _, hr = mg.loss_inputs(2, 320, 320, seed)
+        lr = (hr.reshape(2, 160, 2, 160, 2).sum((2, 4)) / 4).astype(np.float32)
+        batches.append((torch.from_numpy(lr).cuda()[:, None], torch.from_numpy(hr).cuda()[:, None]))
+    preds = []
+    for b in batches:
+        model.validation_step(b)
+        with torch.no_grad():
+            preds.append(model(b[0])[:, 0].cpu().numpy())
+    logged = {k: float(v) for k, v in model.on_validation_epoch_end().items()}
+    pairs = [(p, b[1][:, 0].cpu().numpy()) for p, b in zip(preds, batches)]
+    want = ol.metric_epoch(pairs)
+    w, corr = ol.effective_weights(cfg.model_dump(), sc)
+    want_loss = sum(wt * want[k] for k, wt in w.items()) + (corr if corr > 0 else 0.0)
+    assert abs(logged["val/loss"] - want_loss) <= 1e-5 * abs(want_loss)
+    for k, v in want.items():
+        assert abs(logged[f"val/linear/{k}"] - v) <= 5e-6 * max(1.0, abs(v)), k
+    ups = [(np.repeat(np.repeat(b[0][:, 0].cpu().numpy(), 2, 1), 2, 2) / 4, b[1][:, 0].cpu().numpy()) for b in batches]
+    want_in = ol.metric_epoch(ups)
+    for k, v in want_in.items():
+        assert abs(logged[f"val/linear/in/{k}"] - v) <= 5e-6 * max(1.0, abs(v)), k
+    assert model.in_metrics is None and model.metrics is not None      # input metrics are dropped after the first epoch

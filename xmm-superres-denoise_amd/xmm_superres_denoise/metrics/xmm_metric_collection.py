@@ -19,35 +19,9 @@ from typing import List
 
 import torch
 
-from ..utils.loss_functions import Loss
+from ..utils.loss_functions import EpochState, Loss
 
 NAMES = ("psnr", "ssim", "ms_ssim", "l1", "l2", "poisson")
-
-
-class _State:
-    def __init__(self):
-        self.acc = None      # device tensor: [sse, n, tmin, tmax, ssim_sum, ms_sum, nimg, abs_sum, poisson_sum]
-
-    def add(self, out: torch.Tensor, n: int, nimg: int):
-        # out: [total, l1, poisson, psnr, ssim, ms_ssim, mse, tmin, tmax, ...] of one batch
-        cur = torch.stack([out[6] * n, out.new_tensor(float(n)), out[7], out[8], out[4] * nimg, out[5] * nimg,
-                           out.new_tensor(float(nimg)), out[1] * n, out[2] * nimg]).double()
-        if self.acc is None:
-            zero = torch.zeros((), dtype=torch.float64, device=out.device)
-            cur[2] = torch.minimum(cur[2], zero)     # metric states start at 0
-            cur[3] = torch.maximum(cur[3], zero)
-            self.acc = cur
-        else:
-            a = self.acc
-            self.acc = torch.stack([a[0] + cur[0], a[1] + cur[1], torch.minimum(a[2], cur[2]), torch.maximum(a[3], cur[3]),
-                                    a[4] + cur[4], a[5] + cur[5], a[6] + cur[6], a[7] + cur[7], a[8] + cur[8]])
-
-    def compute(self) -> dict:
-        a = self.acc
-        mse = a[0] / a[1]
-        dr = a[3] - a[2]
-        return {"psnr": 10.0 * (2 * torch.log10(dr) - torch.log10(mse)), "ssim": a[4] / a[6], "ms_ssim": a[5] / a[6],
-                "l1": a[7] / a[1], "l2": mse, "poisson": a[8] / a[6]}
 
 
 class XMMMetricCollection:
@@ -66,7 +40,7 @@ class XMMMetricCollection:
         self.reset()
 
     def reset(self):
-        self.states = {mode: _State() for mode in self.normalizer_dict}
+        self.states = {mode: EpochState() for mode in self.normalizer_dict}
 
     @torch.no_grad()
     def update(self, preds: torch.Tensor, target: torch.Tensor) -> None:

@@ -1,7 +1,7 @@
 """`Model`: the reference's LightningModule (models/model.py:13-247) restated without Lightning for the RRDB paths:
 constructor signature, `configure_model` factory (model.py:153-186), `forward` = clamp(generator(x), 0, 1)
-(model.py:48-49 -- the second clamp is fused in the engine's output kernel and is idempotent), the train branch of
-`_on_step` (model.py:72-86) and `configure_optimizers` (model.py:239-247).
+(model.py:48-49 -- the second clamp is fused in the engine's output kernel and is idempotent), `_on_step` / `_on_epoch_end` (model.py:72-150, returning what the reference logs) and `configure_optimizers`
+(model.py:239-247).
 """
 from __future__ import annotations
 
@@ -61,13 +61,67 @@ class Model(nn.Module):
     def training_step(self, batch, batch_idx=0):
         return self._on_step(batch, "train")
 
+    def on_validation_start(self) -> None:
+        self._on_epoch_end("train")
+
+    def validation_step(self, batch, batch_idx=0):
+        self._on_step(batch, "val")
+
+    def on_validation_epoch_end(self) -> dict:
+        return self._on_epoch_end("val")
+
+    def test_step(self, batch, batch_idx=0):
+        self._on_step(batch, "test")
+
+    def on_test_epoch_end(self) -> dict:
+        return self._on_epoch_end("test")
+
+    def predict_step(self, batch, batch_idx: int = 0, dataloader_idx: int = 0) -> None:
+        batch["preds"] = self(batch["lr"])
+
     def _on_step(self, batch, stage):
+        """reference models/model.py:72-107: train -> loss(preds, target); val/test -> update the epoch states of the
+        loss and of the metric collections (input metrics on the nearest-upsampled low-resolution image)."""
         lr_img, hr_img = batch
         preds = self(lr_img)
         target = hr_img if hr_img is not None else preds
         if stage == "train":
             return self.loss(preds, target)
-        return preds
+        with torch.no_grad():
+            self.loss.update(preds=preds, target=target)
+            if self.in_metrics is not None or self.ext_metrics is not None:
+                scale_factor = target.shape[2] / lr_img.shape[2]
+                if scale_factor != 1.0:
+                    from xmm_superres_denoise.transforms import ImageUpsample
+                    lr_img = ImageUpsample(scale_factor=int(scale_factor))(lr_img)
+            if self.metrics is not None:
+                self.metrics.update(preds=preds, target=target)
+            if self.in_metrics is not None:
+                self.in_metrics.update(preds=lr_img, target=target)
+            if self.ext_metrics is not None:
+                self.ext_metrics.update(preds=preds, target=target)
+            if self.in_ext_metrics is not None:
+                self.in_ext_metrics.update(preds=lr_img, target=target)
+        return None
+
+    def _on_epoch_end(self, stage):
+        """reference models/model.py:109-150 without the Lightning logger: returns what it would log.  Multi-GPU runs
+        reduce the returned values like `sync_dist=True` does (mean over ranks) in the training driver."""
+        if stage == "train":
+            if self.loss is not None:
+                self.loss.reset()
+            return {}
+        logged = {f"{stage}/loss": self.loss.compute()}
+        self.loss.reset()
+        for name in ("metrics", "ext_metrics", "in_metrics", "in_ext_metrics"):
+            coll = getattr(self, name)
+            if coll is not None:
+                logged.update(coll.compute())
+                coll.reset()
+                if name.startswith("in_"):
+                    setattr(self, name, None)      # input metrics are only needed once (reference :135-142)
+        self.logged = logged
+        return logged
 
     def configure_optimizers(self):
         if self.model is None:

@@ -1,1 +1,1 @@
-from .loss_functions import Loss, create_loss, load_loss_config  # noqa: F401
+from .loss_functions import EpochState, Loss, create_loss, load_loss_config  # noqa: F401

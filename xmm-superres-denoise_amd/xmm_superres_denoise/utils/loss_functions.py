@@ -55,6 +55,37 @@ def load_loss_config(scaling: str = "linear", **overrides):
     return sc, LossCfg(**d)
 
 
+class EpochState:
+    """Per-epoch states of the torchmetrics classes behind the loss terms / validation metrics, accumulated on the
+    device from the per-batch result vector of xsd_loss_eval: sum of squared errors and element count, running
+    min/max of the target (both start at 0, PeakSignalNoiseRatio(data_range=None)), per-image ssim / ms_ssim sums,
+    absolute-error sum, sum of per-batch poisson means (metrics/metrics.py:30-39 divides that by the image count)."""
+
+    def __init__(self):
+        self.acc = None      # [sse, n, tmin, tmax, ssim_sum, ms_sum, nimg, abs_sum, poisson_sum]
+
+    def add(self, out: torch.Tensor, n: int, nimg: int):
+        # out: [total, l1, poisson, psnr, ssim, ms_ssim, mse, tmin, tmax, ...] of one batch
+        cur = torch.stack([out[6] * n, out.new_tensor(float(n)), out[7], out[8], out[4] * nimg, out[5] * nimg,
+                           out.new_tensor(float(nimg)), out[1] * n, out[2] * nimg]).double()
+        if self.acc is None:
+            zero = torch.zeros((), dtype=torch.float64, device=out.device)
+            cur[2] = torch.minimum(cur[2], zero)
+            cur[3] = torch.maximum(cur[3], zero)
+            self.acc = cur
+        else:
+            a = self.acc
+            self.acc = torch.stack([a[0] + cur[0], a[1] + cur[1], torch.minimum(a[2], cur[2]), torch.maximum(a[3], cur[3]),
+                                    a[4] + cur[4], a[5] + cur[5], a[6] + cur[6], a[7] + cur[7], a[8] + cur[8]])
+
+    def compute(self) -> dict:
+        a = self.acc
+        mse = a[0] / a[1]
+        dr = a[3] - a[2]
+        return {"psnr": 10.0 * (2 * torch.log10(dr) - torch.log10(mse)), "ssim": a[4] / a[6], "ms_ssim": a[5] / a[6],
+                "l1": a[7] / a[1], "l2": mse, "poisson": a[8] / a[6]}
+
+
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, preds, target, loss, need_grad):
@@ -86,6 +117,7 @@ class Loss:
         check(self.L.xsd_loss_create(ctypes.byref(cfg), ctypes.byref(h)))
         self.h = h
         self.last_values = None   # device tensor [12] of the last call: total, l1, poisson, psnr, ssim, ms_ssim, mse, min/max(target)
+        self._epoch = EpochState()
 
     def __del__(self):
         if getattr(self, "h", None) and self.h.value:
@@ -118,6 +150,24 @@ class Loss:
     def __call__(self, preds: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         need = torch.is_grad_enabled() and preds.requires_grad
         return _LossFn.apply(preds, target, self, need)
+
+    # ---- epoch-level protocol used by the validation / test branches of Model._on_step (models/model.py:87-88,109-120):
+    # the composed metric's compute() is the same weighted sum over the terms' EPOCH-level values
+    @torch.no_grad()
+    def update(self, preds: torch.Tensor, target: torch.Tensor) -> None:
+        out, _ = self._eval(preds.contiguous(), target.contiguous(), False)
+        self.last_values = out
+        self._epoch.add(out, preds.numel(), preds.shape[0])
+
+    def compute(self) -> torch.Tensor:
+        vals = self._epoch.compute()
+        total = sum(w * vals[k] for k, w in self.weights.items() if w != 0.0)
+        if self.correction > 0.0:
+            total = total + self.correction
+        return total.float()
+
+    def reset(self) -> None:
+        self._epoch = EpochState()
 
     def term_values(self) -> dict:
         v = self.last_values.tolist()
