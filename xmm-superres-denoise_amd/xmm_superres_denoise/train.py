@@ -41,7 +41,7 @@ def load_checkpoint(path: str, model: Model, trainer: DataParallelTrainer | None
 
 def fit(name: str = "rrdb_denoise", lr_res: int = 416, batch_size: int = 4, steps: int = 10, device: str | None = None,
         checkpoint: str | None = None, seed: int = 0, math: str | None = None, log_every: int = 1,
-        loss: str = "l1", scaling: str = "linear"):
+        loss: str = "l1", scaling: str = "linear", val_batches: int = 0):
     """loss: "l1" (BASELINE configs[2]) or "paper" = the reference's shipped default, 0.5 psnr + 0.5 ms_ssim with the
     scaling table of the dataset's stretch mode (`scaling`; res/configs/loss_functions.toml, train.py:46-63)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -55,11 +55,18 @@ def fit(name: str = "rrdb_denoise", lr_res: int = 416, batch_size: int = 4, step
     cfg = model_cfg(name, batch_size=batch_size)
     hr_res = lr_res * (2 if name == "esr_gen" else 1)
     torch.manual_seed(seed)
+    from xmm_superres_denoise.utils import Loss, create_loss, load_loss_config
     loss_fn = None
     if loss != "l1":
-        from xmm_superres_denoise.utils import create_loss, load_loss_config
         loss_fn = create_loss(*load_loss_config(scaling))
-    model = Model(cfg, (lr_res, lr_res), (hr_res, hr_res), loss=loss_fn, metrics=None, extended_metrics=None,
+    metrics = None
+    if val_batches > 0:   # train.py:86-104 of the reference: metric collections over the scaling normalizers
+        from xmm_superres_denoise.metrics import get_metrics
+        from xmm_superres_denoise.transforms import Normalize
+        norm = Normalize(lr_max=0.0022336, hr_max=0.0022336 if name == "rrdb_denoise" else 0.0005584, stretch_mode=scaling)
+        metrics = get_metrics(norm, [Normalize(norm.lr_max.item(), norm.hr_max.item(), "linear")], "val")
+    model = Model(cfg, (lr_res, lr_res), (hr_res, hr_res), loss=loss_fn if loss_fn is not None else Loss({"l1": 1.0}),
+                  metrics=metrics, extended_metrics=None,
                   in_metrics=None, in_extended_metrics=None)
     model.configure_model()
     model.to(dev)
@@ -76,6 +83,20 @@ def fit(name: str = "rrdb_denoise", lr_res: int = 416, batch_size: int = 4, step
         losses.append(float(loss))
         if rank == 0 and log_every and it % log_every == 0:
             print(f"step {it}: train/loss {losses[-1]:.6f}", flush=True)
+    if val_batches > 0:       # one validation epoch (reference model.py:53-60); values are averaged over ranks like sync_dist
+        model.on_validation_start()
+        for _ in range(val_batches):
+            lr_img = torch.rand((per_rank, 1, lr_res, lr_res), generator=g).to(dev)
+            hr_img = torch.rand((per_rank, 1, hr_res, hr_res), generator=g).to(dev)
+            model.validation_step((lr_img, hr_img))
+        logged = model.on_validation_epoch_end()
+        if world > 1:
+            for k in logged:
+                t = logged[k].detach().float().clone()
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                logged[k] = t / world
+        if rank == 0 and log_every:
+            print("validation: " + ", ".join(f"{k} {float(v):.6f}" for k, v in sorted(logged.items())), flush=True)
     if checkpoint and rank == 0:
         save_checkpoint(checkpoint, model, trainer, epoch=0)
     return model, trainer, losses
@@ -92,8 +113,9 @@ def main():
     ap.add_argument("--math", default=None, choices=[None, "fp32", "bf16x3", "bf16x3_p16"])
     ap.add_argument("--loss", default="l1", choices=["l1", "paper"], help="paper = 0.5 psnr + 0.5 ms_ssim (loss_functions.toml)")
     ap.add_argument("--scaling", default="linear", choices=["linear", "sqrt", "asinh", "log"])
+    ap.add_argument("--val-batches", type=int, default=0, help="validation batches after training (loss + metric set)")
     a = ap.parse_args()
-    fit(a.model, a.lr_res, a.batch_size, a.steps, checkpoint=a.checkpoint, math=a.math, loss=a.loss, scaling=a.scaling)
+    fit(a.model, a.lr_res, a.batch_size, a.steps, checkpoint=a.checkpoint, math=a.math, loss=a.loss, scaling=a.scaling, val_batches=a.val_batches)
     if dist.is_initialized():
         dist.destroy_process_group()
 
