@@ -89,6 +89,7 @@ __global__ __launch_bounds__(RT, 2) void wgrad_p16_kernel(const WgradParams P)
                 __builtin_amdgcn_global_load_lds((gptr_t)(ok ? src + 64 : zero), (lptr_t)(dst + R_XL + g * 1024), 16, 0, 0);
             }
         }
+        if ((P.ablate & 4096) && t != part) return; // diagnostic: stale (but realistic) G tiles after the first
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int g = wv + 8 * k;

@@ -280,7 +280,7 @@ struct Builder {
             wp.partial = eng->wg_partial; wp.bias_partial = eng->wg_bias_partial;
             rp.partial = eng->wg_partial; rp.bias_partial = eng->wg_bias_partial;
             rp.dw = eng->b_grads + w_off; rp.db = eng->b_grads + b_off;
-            wp.zero = eng->zero_page; rp.p16 = eng->math == 2;
+            wp.zero = eng->zero_page; wp.ablate = eng->ablate; rp.p16 = eng->math == 2;
             hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return eng->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, eng->math, s); });
             if (err != hipSuccess) return err;
             return launch_wgrad_reduce(rp, s);

@@ -74,6 +74,8 @@ struct WgradParams {
     float* partial;      // [nparts][n_g][n_in][9][32 ci][32 co]
     float* bias_partial; // [nparts][n_g][32]
     const void* zero;    // zero page (P16 kernel)
+    int ablate;          // diagnostic (env XSD_ABLATE): 4096 = request the G tile only for the first tile of a workgroup
+    int pad_;
 };
 
 struct WgradReduceParams {
