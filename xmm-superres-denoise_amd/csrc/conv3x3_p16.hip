@@ -216,10 +216,20 @@ __global__ __launch_bounds__(QT, 2) void conv3x3_p16_kernel(const ConvParams P)
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * o.slope;
-            if (o.mask) {
+            if (o.bits_in) { // lrelu' from the compact mask written by the forward conv (2 B per lane instead of 64 B)
+                const unsigned int m = o.bits_in[(os >> 5) * 2 + h];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = ((m >> i) & 1u) ? v[i] : v[i] * o.mslope;
+            } else if (o.mask) {
                 load16(o.mask, os, e);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) v[i] = e[i] > 0.f ? v[i] : v[i] * o.mslope;
+            }
+            if (o.bits_out) {
+                unsigned int m = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) m |= (v[i] > 0.f ? 1u : 0u) << i;
+                o.bits_out[(os >> 5) * 2 + h] = (unsigned short)m;
             }
             unsigned int hw[8], lw[8];
 #pragma unroll
@@ -239,12 +249,10 @@ __global__ __launch_bounds__(QT, 2) void conv3x3_p16_kernel(const ConvParams P)
     // after it (input ring depth 3) and the epilogue's stores stay in flight.
     auto wait_and_barrier = [&](int young) {
         switch (young) {
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+#define XSD_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+        XSD_VMCNT_CASE(4) XSD_VMCNT_CASE(5) XSD_VMCNT_CASE(8) XSD_VMCNT_CASE(9) XSD_VMCNT_CASE(10) XSD_VMCNT_CASE(12)
+        XSD_VMCNT_CASE(13) XSD_VMCNT_CASE(14) XSD_VMCNT_CASE(15)
+#undef XSD_VMCNT_CASE
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(QT, 2) void conv3x3_p16_kernel(const ConvParams P)
             if (s2 == 1 && s == nsteps - 1) {
                 epilogue(0, cur);
                 const int y = cur.y0 + wv * 2;
-                young += (P.ablate & 4) ? 0 : 4 * ((y < P.H) + (y + 1 < P.H));
+                young += (P.ablate & 4) ? 0 : (4 + (P.out[0].bits_out != nullptr)) * ((y < P.H) + (y + 1 < P.H));
             }
             if (more) wait_and_barrier(young);
             ib = ib == 2 ? 0 : ib + 1;

@@ -234,6 +234,8 @@ struct Builder {
             if (o.e2) o.e2 += (long long)b0 * p.std_bs;
             if (o.e3) o.e3 += (long long)b0 * p.std_bs;
             if (o.mask) o.mask += (long long)b0 * p.std_bs;
+            if (o.bits_out) o.bits_out += (long long)b0 * (p.std_bs / 16);   // 2 half-words per pixel of 32 floats
+            if (o.bits_in) o.bits_in += (long long)b0 * (p.std_bs / 16);
         }
         return p;
     }
@@ -298,7 +300,8 @@ struct Builder {
         F.clear();
         e->bwd_stages.assign(blocks + 2, {});
 
-        struct RdbAct { float* xin; float* xs[4]; float* out; };
+        struct RdbAct { float* xin; float* xs[4]; float* out; unsigned short* xb[4]; };
+        const bool use_bits = train && e->math == 2 && e->p16v2 == 0; // compact lrelu' masks (conv3x3_p16 epilogue)
         std::vector<RdbAct> acts(blocks * 3);
         std::vector<float*> rin(blocks + 1);
 
@@ -326,7 +329,11 @@ struct Builder {
                     p.wpanel = fwdp(cw.fwd_off);
                     float* o = alloc(0);
                     std_out(p.out[0], o, 0);
-                    if (c < 4) { p.out[0].slope = 0.2f; a.xs[c] = o; }     // rrdb_blocks.py:38-52
+                    if (c < 4) {                                            // rrdb_blocks.py:38-52
+                        p.out[0].slope = 0.2f; a.xs[c] = o;
+                        a.xb[c] = use_bits ? reinterpret_cast<unsigned short*>(alloc1(0)) : nullptr;
+                        p.out[0].bits_out = a.xb[c];
+                    }
                     else {
                         p.out[0].a1 = 0.2f; p.out[0].e1 = a.xin; p.out[0].s1 = 1.f;           // x5*0.2 + x   (:54)
                         if (r == 2) { p.out[0].a2 = 0.2f; p.out[0].e2 = rin[i]; p.out[0].s2 = 1.f; } // out*0.2 + x (:70)
@@ -490,7 +497,7 @@ struct Builder {
                     if (j == 0) {
                         o.e1 = dOut; o.s1 = r == 2 ? 0.2f : 1.f;
                         if (r == 0) { o.e2 = dR; o.s2 = 1.f; if (i == 0) { o.e3 = dT; o.s3 = 1.f; } }
-                    } else { o.mask = xpl[j]; o.mslope = 0.2f; }
+                    } else { o.mask = xpl[j]; o.mslope = 0.2f; o.bits_in = a.xb[j - 1]; }
                     S.push_back(conv_launch(p, false, 0));
                 }
                 if (dOut != dR) release(dOut, 0, true);

@@ -41,6 +41,11 @@ struct OutDesc {
     const float* mask;
     float a1, s1, a2, s2, s3, slope, mslope;
     int accumulate;
+    // Compact lrelu' masks (math mode 2, training): bit i of the 16-bit word [pixel][lane half h] says whether the stored
+    // value at P16 position 16h + i is > 0.  A conv that produces an activation writes them (bits_out, 4 B per pixel);
+    // the input-gradient conv masked by that activation reads them (bits_in) instead of the 128 B-per-pixel plane.
+    unsigned short* bits_out;
+    const unsigned short* bits_in;
 };
 
 struct ConvParams {
