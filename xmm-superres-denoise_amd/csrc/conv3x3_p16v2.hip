@@ -339,6 +339,14 @@ __global__ __launch_bounds__(TT, 2) void conv3x3_p16v2_kernel(const ConvParams P
                 asm volatile("" ::"v"(h0), "v"(h1), "v"(l0), "v"(l1));
                 continue;
             }
+            if (P.ablate & 512) { // diagnostic: the same store instructions into a 64 KiB window per workgroup (stays in L2)
+                char* rowb = reinterpret_cast<char*>(o.p) + (long long)blockIdx.x * 65536 + (wv * RPW + r) * 4096 + lane * 16;
+                *reinterpret_cast<u32x4*>(rowb) = h0;
+                *reinterpret_cast<u32x4*>(rowb + 1024) = h1;
+                *reinterpret_cast<u32x4*>(rowb + 2048) = l0;
+                *reinterpret_cast<u32x4*>(rowb + 3072) = l1;
+                continue;
+            }
             if (P.ablate & 128) { // diagnostic: the same bytes of the same row, permuted so every store instruction is 1 KiB contiguous
                 char* rowb = reinterpret_cast<char*>(dst + (long long)y * o.rs + (long long)T.x0 * o.ps) + lane * 16;
                 *reinterpret_cast<u32x4*>(rowb) = h0;
