@@ -41,7 +41,11 @@ __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) v += srow[tap / 3][x + tap % 3] * w4[tap];
             const long long o = rbase + (long long)x * 32;
-            if (P.mask) {
+            if (P.bits) {
+                const unsigned int m = (unsigned int)P.bits[((long long)row * P.W + x) * 2 + (q & 1)] >> (4 * (q >> 1));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = ((m >> i) & 1u) ? v[i] : v[i] * P.mslope;
+            } else if (P.mask) {
                 const f32x4 m = P.p16 ? p16_load4(reinterpret_cast<const char*>(P.mask + o), ppos)
                                       : *reinterpret_cast<const f32x4*>(P.mask + o + q * 4);
 #pragma unroll

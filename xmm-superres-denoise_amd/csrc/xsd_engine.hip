@@ -367,6 +367,7 @@ struct Builder {
 
         std::vector<float*> U(nup, nullptr);
         float* H1 = nullptr;
+        unsigned short* h1bits = nullptr; // compact lrelu' mask of H1
         float* pre = nullptr;
         const int lo = nup; // output level
         if (sr) {
@@ -386,6 +387,7 @@ struct Builder {
                 ConvParams p = conv_base(lo);
                 p.n_in = 1; p.n_out = 1; p.in[0] = std_in(feat, lo); p.wpanel = fwdp(e->hr.fwd_off);
                 std_out(p.out[0], H1, lo); p.out[0].slope = 0.2f;
+                if (use_bits) { h1bits = reinterpret_cast<unsigned short*>(alloc1(lo)); p.out[0].bits_out = h1bits; }
                 F.push_back(conv_launch(p, true, e->hr.b_off));
             }
             if (nup > 0) release(U[nup - 1], lo); else release(T, 0);
@@ -424,7 +426,7 @@ struct Builder {
                 float* GH = alloc(lo);
                 { // d(H1) masked by lrelu'(0.2)
                     EdgeExpandParams p; memset(&p, 0, sizeof(p)); p.p16 = e->math == 2;
-                    p.B = B; p.H = H << lo; p.W = W << lo; p.s = dpre; p.w = e->pk_edge + 3 * 288; p.out = GH; p.mask = H1; p.mslope = 0.2f;
+                    p.B = B; p.H = H << lo; p.W = W << lo; p.s = dpre; p.w = e->pk_edge + 3 * 288; p.out = GH; p.mask = H1; p.mslope = 0.2f; p.bits = h1bits;
                     S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
                 }
                 const float* hr_in = nup > 0 ? U[nup - 1] : T;

@@ -116,6 +116,7 @@ struct EdgeExpandParams { // 1 -> 32 conv:  out[p][c] = bias[c] + sum_tap s[p+ta
     const float* mask;   // plane or null
     float mslope;
     int p16;             // planes (out, mask) are P16
+    const unsigned short* bits; // compact form of `mask` (OutDesc::bits_out layout) or null
 };
 struct EdgeReduceParams { // 32 -> 1 conv: pre[p] = bias + sum_tap sum_c f[p+tap][c] * w[tap][c] (+ skip[p]); y = clamp(pre)
     int B, H, W;
