@@ -154,6 +154,9 @@ int xsd_profile_read(xsd_engine* e, int klass, double* total_ms, int64_t* launch
 int xsd_debug_stamps(xsd_engine* e, int enable, unsigned long long* out8);
 /* Diagnostic only: hipOccupancyMaxActiveBlocksPerMultiprocessor of the split forward conv kernel at a dynamic LDS size. */
 int xsd_debug_occupancy(int lds_bytes);
+/* Diagnostic only: wall time (ms) of a grid of `grid` workgroups that each sleep `us` microseconds holding `lds_bytes` of LDS
+ * (a census of how many such workgroups are resident at once). */
+float xsd_debug_residency_ms(int grid, int threads, int lds_bytes, int us);
 
 /* Single-layer entry points used by the kernel-level parity tests (one 3x3 conv over NHWC 32-channel planes).
  * dev_in: [n_in] plane pointers on the host (each plane [B][H][W][32]); w_oihw: device OIHW [32*n_out][32*n_in][3][3]. */
