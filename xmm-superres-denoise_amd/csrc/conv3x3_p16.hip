@@ -166,6 +166,51 @@ __global__ __launch_bounds__(QT, 2) void conv3x3_p16_kernel(const ConvParams P)
         }
     };
 
+    // Row-reuse form of the same half-step: the half-panel's 18 weight fragments stay in registers and the 4 input rows of
+    // the wave's 2 output rows are walked once, each input fragment feeding every output row that uses it (42 instead of
+    // 54 LDS fragment reads per half-step; same 54 MFMAs, same summation order per accumulator is NOT required: fp32 sums
+    // of the three bf16 products commute up to rounding, covered by the parity tolerances).
+    auto compute_rows = [&](int ibuf, int wbuf) {
+        const char* inb = smem + ibuf * QIN_BYTES;
+        const char* wl = smem + (wbuf ? Q_W1 : Q_W0) + lane * 16;
+        bf16x8 w[9][2];
+        bf16x8 x[3][2];
+        constexpr int kRow[4] = {1, 2, 0, 3};   // rows shared by both output rows first
+        auto load_w = [&](int tap) {
+#pragma unroll
+            for (int part = 0; part < 2; ++part) w[tap][part] = *reinterpret_cast<const bf16x8*>(wl + (tap * 2 + part) * 1024);
+        };
+        auto load_x = [&](int step, int set) {
+            const int ri = kRow[step / 3], dx = step % 3;
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+                x[set][part] = *reinterpret_cast<const bf16x8*>(inb + abase[dx][part] + ri * QROWB);
+        };
+        // step 0 = (input row 1, dx 0) feeds output row 0 with tap (1,0) and output row 1 with tap (0,0)
+        load_x(0, 0); load_w(0); load_w(3);
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(1, 1); load_w(1); load_w(4); load_w(6);
+#pragma unroll
+        for (int step = 0; step < 12; ++step) {
+            const int set = step % 3;
+            const int ri = kRow[step / 3], dx = step % 3;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int r = ri - dy;
+                    if (r < 0 || r >= 2) continue;
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[dy * 3 + dx][term == 1 ? 1 : 0], x[set][term == 0 ? 1 : 0],
+                                                                     acc[r], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (step == 0) { load_w(7); load_x(2, 2); load_w(2); }
+            if (step == 1) { load_w(5); load_w(8); }
+            if (step + 3 < 12) load_x(step + 3, set);
+        }
+    };
+
     // ---- epilogue over P16 planes
     auto load16 = [&](const float* plane, long long px_floats, float (&v)[16]) {
         const char* px = reinterpret_cast<const char*>(plane + px_floats) + h * 32;
@@ -324,7 +369,7 @@ __global__ __launch_bounds__(QT, 2) void conv3x3_p16_kernel(const ConvParams P)
             if (more) dma_w(s_n, s2 ^ 1, s2 ^ 1);              // read by half-step u+1: issued FIRST
             if (u + 2 < nhalf) { dma_next_in(db); young = (P.ablate & 1) ? 0 : n_in_chunks; db = db == 2 ? 0 : db + 1; } // read by u+2
             if (s2 == 0 && s == 0) init_acc(0);
-            if (!(P.ablate & 8)) compute(ib, s2);
+            if (!(P.ablate & 8)) { if (P.ablate & 16384) compute(ib, s2); else compute_rows(ib, s2); }
             if (s2 == 1 && s == nsteps - 1) {
                 epilogue(0, cur);
                 const int y = cur.y0 + wv * 2;

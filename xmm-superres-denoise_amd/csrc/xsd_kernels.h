@@ -62,7 +62,8 @@ struct ConvParams {
                          // 4 skip the epilogue, 8 skip the MFMA loop; role-split kernel only: 16 two of three products,
                          // 32 idle sleep instead of the MFMA loop (with 8), 64 epilogue without its stores, 128 permuted
                          // fully coalesced stores, 256 fill LDS with realistic operand bits, 512 stores into an
-                         // L2-resident 64 KiB window per workgroup
+                         // L2-resident 64 KiB window per workgroup; conv3x3_p16: 16384 tap-major MFMA loop instead of the
+                         // row-reuse loop; wgrad_p16: 4096 G tile requested once per workgroup
     int pad_;
     const void* zero;    // >= 64 B of zeros in HBM (math mode 2: DMA source for zero padding)
     unsigned long long* dbg; // diagnostic phase stamps (null in production): [grid][8] accumulated shader cycles
