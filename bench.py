@@ -243,7 +243,8 @@ def main():
                                     "sr_train": "XMM-SuperRes 2x train step (%s + Adam)" % ("L1" if args.loss == "l1" else "0.5 PSNR + 0.5 MS-SSIM"),
                                     "dn_fwd": "XMM-DeNoise forward", "sr_fwd": "XMM-SuperRes 2x generator forward"}[args.workload],
                        "tile": f"1x{TILE}x{TILE}", "per_gpu_batch": B, "global_batch": B * world,
-                       "net": "RRDB nf=32 x 4 blocks", "math": args.math, "parallelism": f"dp{world}"},
+                       "layers": "RRDB generator, 32 filters x 4 blocks (res/configs/models.toml)", "math": args.math,
+                       "parallelism": f"dp{world}"},
         }
         if prof is not None and prof[0]["launches"] > 0:
             k = prof[0]
