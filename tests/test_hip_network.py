@@ -283,3 +283,53 @@ def test_memory_efficient_recompute_matches_full_batch(kind, monkeypatch):
     la, lb = float(ta.train_step(x, t)), float(tb.train_step(x, t))
     assert la == lb
     assert (ta.grads - tb.grads).abs().max().item() <= 2e-6 * ta.grads.abs().max().item()
+
+
+def test_two_forwards_before_backward_are_reentrant():
+    """y1 = m(x1); y2 = m(x2); (l1 + l2).backward(): the engine holds ONE saved activation set, so the context of y1 must
+    notice that it was displaced and recompute instead of using x2's activations (different shapes on purpose: using
+    the wrong set would index out of bounds).  Gradients must equal the sum of two separate passes."""
+    state = gc.make_state("dn", 32, 1, 41)
+    m = build_module("dn", 1, 1, state).set_math("fp32")
+    x1 = torch.from_numpy(gc.make_input((2, 1, 24, 40), 42)).cuda()
+    x2 = torch.from_numpy(gc.make_input((1, 1, 33, 19), 43)).cuda()
+    t1, t2 = torch.rand_like(x1), torch.rand_like(x2)
+
+    def separate(x, t):
+        for p in m.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        torch.nn.functional.l1_loss(m(xi), t).backward()
+        return xi.grad.clone(), torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+
+    dx1, g1 = separate(x1, t1)
+    dx2, g2 = separate(x2, t2)
+    for p in m.parameters():
+        p.grad = None
+    a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    y1 = m(a)
+    y2 = m(b)
+    (torch.nn.functional.l1_loss(y1, t1) + torch.nn.functional.l1_loss(y2, t2)).backward()
+    g = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    assert torch.equal(a.grad, dx1) and torch.equal(b.grad, dx2)
+    assert (g - (g1 + g2)).abs().max().item() <= 1e-6 * (g1 + g2).abs().max().item()
+
+
+def test_backward_rejects_mismatched_dy_and_stale_generation():
+    from xmm_superres_denoise.engine import XsdError
+    state = gc.make_state("dn", 32, 1, 41)
+    m = build_module("dn", 1, 1, state)
+    eng = m._get_engine(torch.device("cuda", 0))
+    eng.pack(m.flat_parameters())
+    x = torch.rand(2, 1, 24, 40, device="cuda")
+    y = eng.forward(x, save_for_backward=True)
+    gen = eng.generation
+    grads = torch.empty_like(m.flat_parameters())
+    with pytest.raises(XsdError, match="dy has shape"):
+        eng.backward(torch.zeros(1, 1, 24, 40, device="cuda"), grads)
+    eng.forward(torch.rand(1, 1, 16, 32, device="cuda"), save_for_backward=True)
+    with pytest.raises(XsdError, match="later forward replaced"):
+        eng.backward(torch.zeros_like(y), grads, generation=gen)
+    eng.forward(x, save_for_backward=False)
+    with pytest.raises(XsdError, match="preceding forward"):
+        eng.backward(torch.zeros_like(y), grads)

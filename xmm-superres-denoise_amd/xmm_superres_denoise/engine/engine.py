@@ -40,6 +40,13 @@ class Engine:
         self.scale = 2 ** num_upsample if kind == "sr" else 1
         self.nparams = int(self.L.xsd_param_count(self.h))
         self.num_stages = int(self.L.xsd_backward_num_stages(self.h))
+        # The engine keeps ONE set of saved activations (one plan / workspace).  Every forward that saves them gets a new
+        # generation id; a backward must name the generation it belongs to (autograd contexts do) and is refused when a
+        # later forward has replaced the activations or when dy does not have the saved output's shape.
+        self.generation = 0
+        self._saved_gen = None
+        self._saved_out_shape = None
+        self._x_ref = None
 
     def __del__(self):
         try:
@@ -75,18 +82,47 @@ class Engine:
         B, _, H, W = x.shape
         y = torch.empty((B, 1, H * self.scale, W * self.scale), device=x.device, dtype=torch.float32)
         check(self.L.xsd_forward(self.h, x.data_ptr(), y.data_ptr(), B, H, W, int(save_for_backward), _stream_ptr(x.device)))
+        # any forward rebuilds / reuses the workspace, so previously saved activations are gone either way
         self._x_ref = x if save_for_backward else None  # conv_first's weight gradient re-reads x
+        self._saved_out_shape = tuple(y.shape) if save_for_backward else None
+        if save_for_backward:
+            self.generation += 1
+            self._saved_gen = self.generation
+        else:
+            self._saved_gen = None
         return y
 
-    def backward(self, dy: torch.Tensor, flat_grads: torch.Tensor, need_dx: bool = False):
+    def has_saved(self, generation: int) -> bool:
+        """True while the activations saved by forward number `generation` are still the engine's current ones."""
+        return generation is not None and self._saved_gen == generation
+
+    def _check_backward_args(self, dy, flat_grads, dx, generation):
         _require_cuda_f32(dy, "dy")
         _require_cuda_f32(flat_grads, "flat_grads")
+        if self._saved_gen is None:
+            raise XsdError("backward needs a preceding forward(save_for_backward=True) whose activations are still held")
+        if generation is not None and generation != self._saved_gen:
+            raise XsdError(f"backward for forward #{generation}, but the engine holds the activations of forward "
+                           f"#{self._saved_gen}: a later forward replaced them (one saved activation set per engine)")
+        if tuple(dy.shape) != self._saved_out_shape:
+            raise XsdError(f"dy has shape {tuple(dy.shape)}, the saved forward produced {self._saved_out_shape}")
+        if flat_grads.numel() != self.nparams:
+            raise XsdError(f"flat_grads has {flat_grads.numel()} elements, engine expects {self.nparams}")
+        if dx is not None:
+            _require_cuda_f32(dx, "dx")
+            if tuple(dx.shape) != tuple(self._x_ref.shape):
+                raise XsdError(f"dx has shape {tuple(dx.shape)}, the saved input has {tuple(self._x_ref.shape)}")
+
+    def backward(self, dy: torch.Tensor, flat_grads: torch.Tensor, need_dx: bool = False, generation: int | None = None):
+        self._check_backward_args(dy, flat_grads, None, generation)
         dx = torch.empty_like(self._x_ref) if need_dx else None
         check(self.L.xsd_backward(self.h, dy.data_ptr(), dx.data_ptr() if need_dx else None, flat_grads.data_ptr(),
                                   _stream_ptr(dy.device)))
         return dx
 
-    def backward_stage(self, stage: int, dy: torch.Tensor, flat_grads: torch.Tensor, dx: torch.Tensor | None = None):
+    def backward_stage(self, stage: int, dy: torch.Tensor, flat_grads: torch.Tensor, dx: torch.Tensor | None = None,
+                       generation: int | None = None):
+        self._check_backward_args(dy, flat_grads, dx, generation)
         check(self.L.xsd_backward_stage(self.h, stage, dy.data_ptr(), dx.data_ptr() if dx is not None else None,
                                         flat_grads.data_ptr(), _stream_ptr(dy.device)))
 

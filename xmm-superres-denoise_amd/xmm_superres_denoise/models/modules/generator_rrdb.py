@@ -71,22 +71,40 @@ class _EngineFn(torch.autograd.Function):
         ctx.module = module
         ctx.need_dx = x.requires_grad
         ctx.recompute = bool(need and module.memory_efficient)
+        ctx.flat_version = module._flat._version
+        if need:
+            ctx.save_for_backward(x)   # 1 channel: 1/2000 of the activations; lets a displaced context recompute
         if ctx.recompute:
-            ctx.save_for_backward(x)
+            ctx.generation = None
             return forward_chunked(eng, x.contiguous(), me_chunk())
-        return eng.forward(x.contiguous(), save_for_backward=need)
+        y = eng.forward(x.contiguous(), save_for_backward=need)
+        ctx.generation = eng.generation if need else None
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         m = ctx.module
         eng = m._engine
         grads = torch.empty_like(m._flat)
+        (x,) = ctx.saved_tensors
+        if tuple(dy.shape) != (x.shape[0], 1, x.shape[2] * eng.scale, x.shape[3] * eng.scale):
+            raise XsdError(f"dy has shape {tuple(dy.shape)} for an input of shape {tuple(x.shape)}")
+        stale = not ctx.recompute and not eng.has_saved(ctx.generation)
+        if (ctx.recompute or stale) and m._flat._version != ctx.flat_version:
+            # same rule as torch's saved-tensor version check: the forward must be re-run with the weights it saw
+            raise XsdError("parameters were modified in place between forward and backward of a pass whose activations "
+                           "have to be recomputed (memory_efficient, or a later forward displaced them)")
         if ctx.recompute:
-            (x,) = ctx.saved_tensors
             eng.pack(m._flat)
             dx = backward_recompute(eng, x.contiguous(), dy.contiguous(), grads, ctx.need_dx, me_chunk())
+        elif stale:
+            # another forward of this module ran in between (y1 = m(x1); y2 = m(x2); (l1 + l2).backward()): the engine
+            # holds one activation set, so re-run this context's forward from its saved input, then its backward
+            eng.pack(m._flat)
+            eng.forward(x.contiguous(), save_for_backward=True)
+            dx = eng.backward(dy.contiguous(), grads, need_dx=ctx.need_dx, generation=eng.generation)
         else:
-            dx = eng.backward(dy.contiguous(), grads, need_dx=ctx.need_dx)
+            dx = eng.backward(dy.contiguous(), grads, need_dx=ctx.need_dx, generation=ctx.generation)
         outs, off = [], 0
         for p in m._plist:
             n = p.numel()
