@@ -62,8 +62,13 @@ int64_t xsd_param_count(const xsd_engine* e);
  * 2 = "bf16x3_p16": the same arithmetic, but every feature plane is kept pre-split in HBM (P16 format, csrc/p16.h:
  * per pixel 32 x bf16 hi | 32 x bf16 lo in accumulator channel order, same 128 B) so tiles move HBM -> LDS by LDS-DMA with
  * no staging instructions; activations carry 16 significant bits (whole-net error ~5e-6 of max).
- * Default from the environment variable XSD_MATH ("fp32" | "bf16x3" | "bf16x3_p16").  Changing it invalidates the
- * packed weights and the plan. */
+ * 3 = "bf16x6": fp32-CLASS arithmetic on the bf16 matrix cores: every fp32 operand is split exactly into three bf16
+ * terms and a product is six bf16 MFMA products (dropped terms <= 2^-23 relative); v_mfma_f32_32x32x16_bf16 sums its 16
+ * products and the fp32 accumulator exactly and rounds once, so against float64 this mode is at least as accurate as
+ * mode 0 and as the reference's fp32 nn.Conv2d (tests/test_hip_precision.py).  Planes stay fp32.
+ * Modes 0 and 3 carry the reference's fp32 precision; modes 1 and 2 carry 16-bit significands (tolerance-only parity).
+ * Default from the environment variable XSD_MATH ("fp32" | "bf16x6" | "bf16x3" | "bf16x3_p16").  Changing it invalidates
+ * the packed weights and the plan. */
 int xsd_set_math(xsd_engine* e, int mode);
 int xsd_get_math(const xsd_engine* e);
 

@@ -1,0 +1,130 @@
+"""Is math mode "bf16x6" (exact 3-term bf16 split, six products, MFMA accumulation) fp32-CLASS?  Evidence against a float64
+evaluation of the same network, next to the two things that define "the reference's precision": torch's own fp32 path on
+the CPU (the reference's nn.Conv2d arithmetic, rrdb_blocks.py:27-54) and this engine's exact-fp32 MFMA mode.
+The claim tested: error(bf16x6 vs float64) <= error(torch fp32 vs float64), on single layers, on the golden cases and on a
+512 x 512 four-block generator, forward and backward.  The 16-bit modes (bf16x3, bf16x3_p16) fail the same inequality by an
+order of magnitude, which is why they are not the headline (asserted too, so the distinction stays measured)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gen_common as gc
+from oracle import oracle
+from util_hip import build_module, load_case, nchw_to_planes, planes_to_nchw, ptr_array
+
+pytestmark = pytest.mark.gpu
+
+
+def _rms(a, ref):
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return float(np.sqrt(np.mean((a - ref) ** 2)) / (np.sqrt(np.mean(ref ** 2)) + 1e-300))
+
+
+def _state_t(state, dtype):
+    return {k: torch.from_numpy(v).to(dtype) for k, v in state.items()}
+
+
+def test_mfma_accumulation_is_single_rounding():
+    """The property the mode rests on (tools/mfma_probe.hip measures the instruction itself): a K = 1440 reduction whose
+    exact value needs more than 24 bits comes out closer to float64 from the bf16x6 conv than from an fp32 fma chain."""
+    from xmm_superres_denoise.engine import Engine
+    from xmm_superres_denoise.engine._lib import check
+    rng = np.random.default_rng(5)
+    B, H, W, n_in = 1, 32, 64, 5
+    x = rng.normal(size=(B, 32 * n_in, H, W)).astype(np.float32)
+    w = (rng.normal(size=(32, 32 * n_in, 3, 3)) / np.sqrt(288 * n_in)).astype(np.float32)
+    b = rng.normal(size=(32,)).astype(np.float32)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1).numpy()
+    t32 = torch.nn.functional.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), padding=1).numpy()
+    errs = {"torch_fp32": _rms(t32, ref)}
+    xin = nchw_to_planes(x)
+    wd, bd = torch.from_numpy(w).cuda(), torch.from_numpy(b).cuda()
+    for math in ("fp32", "bf16x6", "bf16x3"):
+        e = Engine("dn", 1, 1, 32, 1)
+        e.set_math(math)
+        out = [torch.full((B, H, W, 32), float("nan"), device="cuda")]
+        check(e.L.xsd_test_conv3x3(e.h, ptr_array(xin), n_in, wd.data_ptr(), bd.data_ptr(), ptr_array(out), 1, 1.0, B, H, W, None))
+        errs[math] = _rms(planes_to_nchw(out), ref)
+    print("single conv K=1440 rms error vs float64:", errs)
+    # fp32 fma chain of 1440 terms (this engine's exact-fp32 MFMA mode, bitwise an fmaf chain): ~8e-7; bf16x6: ~3e-7.
+    # torch's CPU kernel (oneDNN) keeps 16 SIMD partial sums per output and lands at ~1.6e-7 on this worst-case layer; on
+    # whole networks, where the fp32 rounding of the stored activations dominates, bf16x6 is below it (tests below).
+    assert errs["bf16x6"] <= 0.5 * errs["fp32"]
+    assert errs["bf16x6"] <= 2.0 * errs["torch_fp32"]
+    assert errs["bf16x3"] > 5 * errs["torch_fp32"]          # 16-bit significands: not fp32-class
+
+
+@pytest.mark.parametrize("name,kind", [("dn_nf32_b4_32x32", "dn"), ("sr_nf32_b4_24x40", "sr")])
+def test_golden_cases_error_vs_float64(name, kind):
+    z, nf, blocks, nup, state, x, t = load_case(name, kind)
+    y64 = oracle.torch_forward(kind, 32, blocks, _state_t(state, torch.float64), torch.from_numpy(x).double(), num_upsample=nup).numpy()
+    y32 = oracle.torch_forward(kind, 32, blocks, _state_t(state, torch.float32), torch.from_numpy(x), num_upsample=nup).numpy()
+    errs = {"torch_fp32": _rms(y32, y64), "golden(reference fp32)": _rms(z["y"], y64)}
+    for math in ("fp32", "bf16x6", "bf16x3_p16"):
+        m = build_module(kind, blocks, nup, state).set_math(math)
+        with torch.no_grad():
+            errs[math] = _rms(m(torch.from_numpy(x).cuda()).cpu().numpy(), y64)
+    print(name, "output rms error vs float64:", errs)
+    assert errs["bf16x6"] <= errs["torch_fp32"]
+    assert errs["bf16x6"] <= errs["golden(reference fp32)"]
+    assert errs["bf16x6"] <= errs["fp32"]
+    assert errs["bf16x3_p16"] > 5 * errs["torch_fp32"]
+
+
+def _net_errors(size, blocks, seed, with_grad):
+    kind = "dn"
+    state = gc.make_state(kind, 32, blocks, seed, gain=1.0)
+    x = gc.make_input((1, 1, size, size), seed + 1)
+    dy = (gc.make_input((1, 1, size, size), seed + 2) - 0.5).astype(np.float32) / (size * size)
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+
+    def torch_path(dtype):
+        st = {k: v.requires_grad_(with_grad) for k, v in _state_t(state, dtype).items()}
+        xt = torch.from_numpy(x).to(dtype).requires_grad_(with_grad)
+        y = oracle.torch_forward(kind, 32, blocks, st, xt)
+        g = dx = None
+        if with_grad:
+            y.backward(torch.from_numpy(dy).to(dtype))
+            g = torch.cat([v.grad.reshape(-1) for v in st.values()]).numpy()
+            dx = xt.grad.numpy()
+        return y.detach().numpy(), g, dx
+
+    y64, g64, dx64 = torch_path(torch.float64)
+    y32, g32, dx32 = torch_path(torch.float32)
+    inside = (y64 > 0) & (y64 < 1)          # the clamp hides errors where it saturates: compare where it is the identity
+    out = {"torch_fp32": {"y": _rms(y32[inside], y64[inside])}}
+    if with_grad:
+        out["torch_fp32"].update(g=_rms(g32, g64), dx=_rms(dx32, dx64))
+    for math in ("fp32", "bf16x6", "bf16x3_p16"):
+        m = build_module(kind, blocks, 1, state).set_math(math)
+        eng = m._get_engine(torch.device("cuda", 0))
+        eng.pack(m.flat_parameters())
+        y = eng.forward(torch.from_numpy(x).cuda(), save_for_backward=with_grad)
+        rec = {"y": _rms(y.cpu().numpy()[inside], y64[inside])}
+        if with_grad:
+            grads = torch.empty_like(m.flat_parameters())
+            dx = eng.backward(torch.from_numpy(dy).cuda(), grads, need_dx=True)
+            rec.update(g=_rms(grads.cpu().numpy(), g64), dx=_rms(dx.cpu().numpy(), dx64))
+        out[math] = rec
+    return out, float(inside.mean())
+
+
+def test_full_size_forward_error_vs_float64():
+    """BASELINE tile size, BASELINE depth: 1 x 512 x 512, 4 RRDB blocks (36 dense blocks, K up to 1440 per conv)."""
+    errs, frac = _net_errors(512, 4, 7001, with_grad=False)
+    print(f"512^2 x 4 blocks, forward rms error vs float64 ({100 * frac:.0f}% of pixels unclamped):", errs)
+    assert errs["bf16x6"]["y"] <= errs["torch_fp32"]["y"]
+    assert errs["bf16x6"]["y"] <= errs["fp32"]["y"]
+    assert errs["bf16x3_p16"]["y"] > 5 * errs["torch_fp32"]["y"]
+
+
+def test_backward_error_vs_float64():
+    """256 x 256, 4 blocks, gradient of the linear functional <dy, y> (no loss discontinuity): every parameter gradient and
+    dL/dx against float64 autograd (LeakyReLU' / clamp-mask flips hit every fp32 path alike)."""
+    errs, frac = _net_errors(256, 4, 7101, with_grad=True)
+    print(f"256^2 x 4 blocks, rms errors vs float64 ({100 * frac:.0f}% of pixels unclamped):", errs)
+    for key in ("y", "g", "dx"):
+        assert errs["bf16x6"][key] <= errs["torch_fp32"][key], key
+        assert errs["bf16x6"][key] <= errs["fp32"][key], key

@@ -1,0 +1,234 @@
+// wgrad_s3.hip -- math mode 3 ("bf16x6"): weight gradient of the 3x3 convs over fp32 planes with fp32-class arithmetic
+// on the bf16 matrix cores (3-term exact split of BOTH operands, six products, single-rounding MFMA accumulation: see
+// conv3x3_s3.hip).  Replaces autograd's conv weight-gradient for the reference's nn.Conv2d(32k -> 32n, 3,1,1) layers
+// (rrdb_blocks.py:27-31; generator_rrdb.py:38-44,95,101):
+//     dW[co][ci][tap] = sum_{b,y,x} G[b,y,x,co] * X[b,y+dy-1,x+dx-1,ci],   db[co] = sum G[..,co]
+// GEMM view: M = 32 input channels (one plane), N = 32 output channels, K = pixels; nine 32x32 accumulators (one per
+// tap) per wave, kept in registers across all tiles of the workgroup; wave w owns row w of each 8x32 tile.  Both MFMA
+// operands need K (8 consecutive pixels) contiguous per lane while memory is [pixel][channel], so LDS holds six images
+// [pixel][32 x bf16] (X_hi, X_mid, X_lo, G_hi, G_mid, G_lo; 114,432 B, one workgroup per CU) read with the transposing
+// ds_read_b64_tr_b16.  Fixed-order two-stage reduction (wgrad_reduce_kernel): bitwise reproducible, no atomics.
+#include "xsd_kernels.h"
+
+namespace xsd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int W3_THREADS = 512;
+constexpr int W3_X_SLOTS = HALO_PX * 8;                               // 2720 (pixel, channel quad) slots
+constexpr int W3_X_ROUNDS = (W3_X_SLOTS + W3_THREADS - 1) / W3_THREADS; // 6
+constexpr int W3_G_SLOTS = TILE_H * TILE_W * 8;                       // 2048
+constexpr int W3_G_ROUNDS = W3_G_SLOTS / W3_THREADS;                  // 4
+constexpr int W3_XT = HALO_PX * 64;                                   // 21,760 B per X term image
+constexpr int W3_GT = TILE_H * TILE_W * 64;                           // 16,384 B per G term image
+constexpr int W3_G_OFF = 3 * W3_XT;                                   // 65,280
+constexpr int W3_LDS_BYTES = W3_G_OFF + 3 * W3_GT;                    // 114,432
+
+// exact 3-term split of 4 fp32 values into packed bf16 pairs
+__device__ __forceinline__ void w3_split4(const f32x4& a, u32x2& hi, u32x2& mid, u32x2& lo)
+{
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const float x0 = a[2 * w], x1 = a[2 * w + 1];
+        const unsigned int h0 = __builtin_bit_cast(unsigned short, (__bf16)x0), h1 = __builtin_bit_cast(unsigned short, (__bf16)x1);
+        const float r0 = x0 - __builtin_bit_cast(float, h0 << 16), r1 = x1 - __builtin_bit_cast(float, h1 << 16);
+        const unsigned int m0 = __builtin_bit_cast(unsigned short, (__bf16)r0), m1 = __builtin_bit_cast(unsigned short, (__bf16)r1);
+        const float q0 = r0 - __builtin_bit_cast(float, m0 << 16), q1 = r1 - __builtin_bit_cast(float, m1 << 16);
+        const unsigned int l0 = __builtin_bit_cast(unsigned short, (__bf16)q0), l1 = __builtin_bit_cast(unsigned short, (__bf16)q1);
+        hi[w] = h0 | (h1 << 16);
+        mid[w] = m0 | (m1 << 16);
+        lo[w] = l0 | (l1 << 16);
+    }
+}
+
+// 8 consecutive pixels (k = 8h + 0..7) of this lane's channel from a [pixel][32 x bf16] image
+__device__ __forceinline__ bf16x8 w3_tr_frag(const char* lds_lane_base, int byte_off)
+{
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds_lane_base + byte_off));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds_lane_base + byte_off + 4 * 64));
+    s16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+__global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6; // 0..7 = tile row
+    const int h = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int part = blockIdx.x;
+    const int j = blockIdx.y;  // input plane
+    const int n = blockIdx.z;  // G chunk
+    const PlaneIn xp = P.x[j];
+    const PlaneIn gp = P.g[n];
+    const int ntiles = P.B * P.tilesY * P.tilesX;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f}; // this thread's 4 channels (tid & 7) of the G tiles it stages
+
+    f32x4 px[W3_X_ROUNDS];
+    f32x4 pg[W3_G_ROUNDS];
+
+    auto load_tile = [&](int t) {
+        const int tx = t % P.tilesX;
+        const int t2 = t / P.tilesX;
+        const int ty = t2 % P.tilesY;
+        const int b = t2 / P.tilesY;
+        const int x0 = tx * TILE_W, y0 = ty * TILE_H;
+        const float* xb = xp.p + (long long)b * xp.bs;
+        const float* gb = gp.p + (long long)b * gp.bs;
+#pragma unroll
+        for (int r = 0; r < W3_X_ROUNDS; ++r) {
+            const int slot = r * W3_THREADS + tid;
+            const int p = slot >> 3, c = slot & 7;
+            const int hy = p / HALO_W, hx = p - hy * HALO_W;
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            const bool ok = (slot < W3_X_SLOTS) && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(xb + (long long)gy * xp.rs + gx * xp.ps + c * 4);
+            px[r] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < W3_G_ROUNDS; ++r) {
+            const int slot = r * W3_THREADS + tid;
+            const int p = slot >> 3, c = slot & 7;
+            const int gy = y0 + (p >> 5), gx = x0 + (p & 31);
+            const bool ok = gy < P.H && gx < P.W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(gb + (long long)gy * gp.rs + gx * gp.ps + c * 4);
+            pg[r] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int r = 0; r < W3_X_ROUNDS; ++r) {
+            const int slot = r * W3_THREADS + tid; // = pixel*8 + quad: 8 B per slot in each image
+            if (slot < W3_X_SLOTS) {
+                u32x2 hi, mid, lo;
+                w3_split4(px[r], hi, mid, lo);
+                *reinterpret_cast<u32x2*>(smem + slot * 8) = hi;
+                *reinterpret_cast<u32x2*>(smem + W3_XT + slot * 8) = mid;
+                *reinterpret_cast<u32x2*>(smem + 2 * W3_XT + slot * 8) = lo;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < W3_G_ROUNDS; ++r) {
+            const int slot = r * W3_THREADS + tid;
+            u32x2 hi, mid, lo;
+            w3_split4(pg[r], hi, mid, lo);
+            *reinterpret_cast<u32x2*>(smem + W3_G_OFF + slot * 8) = hi;
+            *reinterpret_cast<u32x2*>(smem + W3_G_OFF + W3_GT + slot * 8) = mid;
+            *reinterpret_cast<u32x2*>(smem + W3_G_OFF + 2 * W3_GT + slot * 8) = lo;
+            bsum += pg[r];
+        }
+    };
+
+    // per-lane base of the transposing reads: lane i of a 16-lane group addresses block row q = i>>2 (pixel) and
+    // columns 4p..4p+3 (p = i&3) of channel group (lane>>4)&1; the lane half h selects pixels +8.
+    const int i16 = lane & 15;
+    const int lane_off = (8 * h + (i16 >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (i16 & 3) * 8;
+    const char* xbase = smem + wv * (HALO_W * 64) + lane_off; // + term image + ((dy*34 + dx + 16*mf) * 64)
+    const char* gbase = smem + W3_G_OFF + wv * (TILE_W * 64) + lane_off;
+
+    int t = part;
+    if (t < ntiles) {
+        load_tile(t);
+        store_tile();
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (; t < ntiles; t += P.nparts) {
+        const bool more = (t + P.nparts < ntiles);
+        if (more) load_tile(t + P.nparts);
+        // Running accumulators take every product: 12 roundings per tile row and tap, against 32 for an fp32 fma chain over
+        // the same 32 pixels (single-layer error vs float64: tools/dbg_layer.py).
+        bf16x8 g[2][3];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int term = 0; term < 3; ++term) g[mf][term] = w3_tr_frag(gbase, term * W3_GT + 16 * mf * 64);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                const int off = (dy * HALO_W + dx + 16 * mf) * 64;
+                const bf16x8 xh = w3_tr_frag(xbase, off);
+                const bf16x8 xm = w3_tr_frag(xbase, W3_XT + off);
+                const bf16x8 xl = w3_tr_frag(xbase, 2 * W3_XT + off);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, g[mf][0], acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, g[mf][2], acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, g[mf][1], acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, g[mf][0], acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, g[mf][1], acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, g[mf][0], acc[tap], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (more) store_tile();
+        __syncthreads();
+    }
+
+    // ---- cross-wave reduction through LDS, one tap at a time (8 waves x 4 KiB), then one coalesced store per tap
+    float* red = reinterpret_cast<float*>(smem);
+    float* outp = P.partial + ((((long long)part * P.n_g + n) * P.n_in + j) * 9) * 1024;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ci = (i & 3) + 8 * (i >> 2) + 4 * h;
+            red[wv * 1024 + ci * 32 + l31] = acc[tap][i];
+        }
+        __syncthreads();
+        for (int e = tid; e < 1024; e += W3_THREADS) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int w = 0; w < W3_THREADS / 64; ++w) sacc += red[w * 1024 + e];
+            outp[tap * 1024 + e] = sacc;
+        }
+        __syncthreads();
+    }
+    if (j == 0) { // bias gradient: thread tid staged channels 4*(tid&7)..+3 of the G tiles
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[tid * 4 + i] = bsum[i];
+        __syncthreads();
+        if (tid < 32) {
+            const int q = tid >> 2, i = tid & 3;
+            float sacc = 0.f;
+            for (int w = 0; w < W3_THREADS / 8; ++w) sacc += red[(w * 8 + q) * 4 + i];
+            P.bias_partial[((long long)part * P.n_g + n) * 32 + tid] = sacc;
+        }
+    }
+}
+
+hipError_t launch_wgrad_s3(const WgradParams& p, hipStream_t stream)
+{
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_s3_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    const dim3 g(p.nparts, p.n_in, p.n_g), b(W3_THREADS);
+    hipLaunchKernelGGL(wgrad_s3_kernel, g, b, W3_LDS_BYTES, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace xsd

@@ -35,6 +35,9 @@ float debug_residency_ms(int grid, int threads, int lds_bytes, int us);
 hipError_t launch_pack_shuffle_bias(const float* b, float* out, hipStream_t s);
 }
 
+static inline long long panel_floats(int math) { return math == 3 ? S3_PANEL_FLOATS : PANEL_FLOATS; }
+static inline long long panel_off(int math, long long off) { return off / PANEL_FLOATS * panel_floats(math); }
+
 static thread_local std::string g_err;
 static int fail(int code, const char* fmt, ...)
 {
@@ -180,13 +183,14 @@ struct Builder {
         freelist[level].push_back(reinterpret_cast<uintptr_t>(p) - base);
     }
 
+    // packed-panel pointers; `off` counts fp32-panel floats (PANEL_FLOATS per panel), mode 3 panels are 1.5x as large
     const float* fwdp(long long off) const
     {
-        return e->math ? reinterpret_cast<const float*>(e->pk_fwd_s) + off : e->pk_fwd + off;
+        return e->math ? reinterpret_cast<const float*>(e->pk_fwd_s) + panel_off(e->math, off) : e->pk_fwd + off;
     }
     const float* bwdp(long long off) const
     {
-        return e->math ? reinterpret_cast<const float*>(e->pk_bwd_s) + off : e->pk_bwd + off;
+        return e->math ? reinterpret_cast<const float*>(e->pk_bwd_s) + panel_off(e->math, off) : e->pk_bwd + off;
     }
     ConvParams conv_base(int level) const
     {
@@ -244,7 +248,7 @@ struct Builder {
         ConvParams p = p_in;
         {
             const int nst = p.n_out > 1 ? p.n_out : p.n_in;
-            for (int i = 0; i < nst; ++i) if (!p.wstep[i]) p.wstep[i] = p.wpanel + (long long)i * PANEL_FLOATS;
+            for (int i = 0; i < nst; ++i) if (!p.wstep[i]) p.wstep[i] = p.wpanel + (long long)i * panel_floats(e->math);
         }
         xsd_engine* eng = e;
         const double px = (double)p.B * p.H * p.W;
@@ -255,7 +259,7 @@ struct Builder {
             p.dbg = eng->dbg;
             p.ablate = eng->ablate;
             p.zero = eng->zero_page;
-            return prof_launch(eng, 0, flop, bytes, s, [&]() { return eng->math == 2 ? ((eng->p16v2 && p.n_out == 1) ? launch_conv3x3_p16v2(p, eng->p16v2 == 2, s) : launch_conv3x3_p16(p, s)) : eng->big ? launch_conv3x3_big(p, eng->math, s) : launch_conv3x3_mfma(p, eng->math, s); });
+            return prof_launch(eng, 0, flop, bytes, s, [&]() { return eng->math == 3 ? launch_conv3x3_s3(p, s) : eng->math == 2 ? ((eng->p16v2 && p.n_out == 1) ? launch_conv3x3_p16v2(p, eng->p16v2 == 2, s) : launch_conv3x3_p16(p, s)) : eng->big ? launch_conv3x3_big(p, eng->math, s) : launch_conv3x3_mfma(p, eng->math, s); });
         };
     }
     // wgrad + fixed-order reduce into the flat gradient vector
@@ -283,7 +287,7 @@ struct Builder {
             rp.partial = eng->wg_partial; rp.bias_partial = eng->wg_bias_partial;
             rp.dw = eng->b_grads + w_off; rp.db = eng->b_grads + b_off;
             wp.zero = eng->zero_page; wp.ablate = eng->ablate; rp.p16 = eng->math == 2;
-            hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return eng->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, eng->math, s); });
+            hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return eng->math == 3 ? launch_wgrad_s3(wp, s) : eng->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, eng->math, s); });
             if (err != hipSuccess) return err;
             return launch_wgrad_reduce(rp, s);
         });
@@ -491,7 +495,7 @@ struct Builder {
                     for (int i = 0; i < 5 - j; ++i) { // step i reads G_{5-i}
                         const int cc = 5 - i;          // 1-based conv whose gradient plane this is
                         p.in[i] = std_in(Gp[cc], 0);
-                        p.wstep[i] = bwdp(cw[cc - 1].bwd_off) + (long long)j * PANEL_FLOATS;
+                        p.wstep[i] = bwdp(cw[cc - 1].bwd_off + (long long)j * PANEL_FLOATS);
                     }
                     p.wpanel = p.wstep[0];
                     OutDesc& o = p.out[0];
@@ -571,7 +575,7 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     if (const char* m = getenv("XSD_CHUNK")) e->chunk = atoi(m);
     if (const char* m = getenv("XSD_P16")) e->p16v2 = strcmp(m, "v3") == 0 ? 2 : strcmp(m, "v2") == 0 ? 1 : 0;
     if (const char* m = getenv("XSD_CONV")) e->big = strcmp(m, "big") == 0 ? 1 : 0;
-    if (const char* m = getenv("XSD_MATH")) e->math = (strcmp(m, "bf16x3_p16") == 0 || strcmp(m, "2") == 0) ? 2 : (strcmp(m, "bf16x3") == 0 || strcmp(m, "1") == 0) ? 1 : 0;
+    if (const char* m = getenv("XSD_MATH")) e->math = (strcmp(m, "bf16x6") == 0 || strcmp(m, "3") == 0) ? 3 : (strcmp(m, "bf16x3_p16") == 0 || strcmp(m, "2") == 0) ? 2 : (strcmp(m, "bf16x3") == 0 || strcmp(m, "1") == 0) ? 1 : 0;
     const int blocks = cfg->num_res_blocks, nup = cfg->kind == XSD_KIND_SR ? cfg->num_upsample : 0;
     long long off = 0, pk = 0, sb = 0;
     take_conv(off, 32, 1, e->first_w, e->first_b);
@@ -610,8 +614,8 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
 #define CK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { int rc = fail(XSD_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); xsd_destroy(e); return rc; } } while (0)
     CK(hipMalloc((void**)&e->pk_fwd, sizeof(float) * pk));
     CK(hipMalloc((void**)&e->pk_bwd, sizeof(float) * pk));
-    CK(hipMalloc((void**)&e->pk_fwd_s, sizeof(float) * pk));
-    CK(hipMalloc((void**)&e->pk_bwd_s, sizeof(float) * pk));
+    CK(hipMalloc((void**)&e->pk_fwd_s, sizeof(float) * panel_off(3, pk)));   // sized for the largest (mode 3) panels
+    CK(hipMalloc((void**)&e->pk_bwd_s, sizeof(float) * panel_off(3, pk)));
     CK(hipMalloc((void**)&e->zero_page, 256));
     CK(hipMemset(e->zero_page, 0, 256));
     CK(hipMalloc((void**)&e->pk_edge, sizeof(float) * 4 * 288));
@@ -642,7 +646,7 @@ int64_t xsd_param_count(const xsd_engine* e) { return e ? e->nparams : 0; }
 
 int xsd_set_math(xsd_engine* e, int mode)
 {
-    if (!e || mode < 0 || mode > 2) return fail(XSD_ERR_ARG, "math mode must be 0 (fp32), 1 (bf16x3) or 2 (bf16x3 over P16 planes)");
+    if (!e || mode < 0 || mode > 3) return fail(XSD_ERR_ARG, "math mode must be 0 (fp32), 1 (bf16x3), 2 (bf16x3 over P16 planes) or 3 (bf16x6, fp32-class)");
     if (mode != e->math) { e->math = mode; e->packed = false; e->pB = 0; e->ptrain = -1; e->fwd_saved = false; }
     return XSD_OK;
 }
@@ -653,7 +657,9 @@ int xsd_pack_weights(xsd_engine* e, const float* dev_params, void* stream)
     if (!e || !dev_params) return fail(XSD_ERR_ARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
     e->params = dev_params;
-    if (e->math == 2)
+    if (e->math == 3)
+        HIPCHK(launch_pack_weights_s3(dev_params, e->descs_dev, e->ndesc, e->pk_fwd_s, e->pk_bwd_s, s));
+    else if (e->math == 2)
         HIPCHK(launch_pack_weights_p16(dev_params, e->descs_dev, e->ndesc, e->pk_fwd_s, e->pk_bwd_s, s));
     else if (e->math == 1)
         HIPCHK(launch_pack_weights_split(dev_params, e->descs_dev, e->ndesc, e->pk_fwd_s, e->pk_bwd_s, s));
@@ -875,14 +881,15 @@ int xsd_profile_read(xsd_engine* e, int klass, double* total_ms, int64_t* launch
 // ---- single-layer test hooks ---------------------------------------------------------------------------------
 static int pack_single(const float* dev_w, int cout, int cin, float** fwd, float** bwd, int math, hipStream_t s)
 {
-    const long long n = (long long)(cout / 32) * (cin / 32) * PANEL_FLOATS;
+    const long long n = (long long)(cout / 32) * (cin / 32) * panel_floats(math);
     PackDesc d; d.src_w = 0; d.dst_fwd = 0; d.dst_bwd = 0; d.cout = cout; d.cin = cin; d.shuffle = 0; d.bwd_scale = 1.f;
     PackDesc* dd = nullptr;
     HIPCHK(hipMalloc((void**)fwd, sizeof(float) * n));
     HIPCHK(hipMalloc((void**)bwd, sizeof(float) * n));
     HIPCHK(hipMalloc((void**)&dd, sizeof(PackDesc)));
     HIPCHK(hipMemcpy(dd, &d, sizeof(d), hipMemcpyHostToDevice));
-    if (math == 2) HIPCHK(launch_pack_weights_p16(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
+    if (math == 3) HIPCHK(launch_pack_weights_s3(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
+    else if (math == 2) HIPCHK(launch_pack_weights_p16(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
     else if (math == 1) HIPCHK(launch_pack_weights_split(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
     else HIPCHK(launch_pack_weights(dev_w, dd, 1, *fwd, *bwd, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -900,7 +907,8 @@ struct TmpPlanes {
 static hipError_t run_conv(xsd_engine* e, ConvParams& p, hipStream_t s)
 {
     p.zero = e->zero_page;
-    for (int i = 0; i < (p.n_out > 1 ? p.n_out : p.n_in); ++i) p.wstep[i] = p.wpanel + (long long)i * PANEL_FLOATS;
+    for (int i = 0; i < (p.n_out > 1 ? p.n_out : p.n_in); ++i) p.wstep[i] = p.wpanel + (long long)i * panel_floats(e->math);
+    if (e->math == 3) return launch_conv3x3_s3(p, s);
     if (e->math == 2) return (e->p16v2 && p.n_out == 1) ? launch_conv3x3_p16v2(p, e->p16v2 == 2, s) : launch_conv3x3_p16(p, s);
     return e->big ? launch_conv3x3_big(p, e->math, s) : launch_conv3x3_mfma(p, e->math, s);
 }
@@ -975,7 +983,7 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
         for (int i = 0; i < n_in; ++i) wp.x[i] = b.std_in(ins[i], 0);
         wp.g[0] = b.std_in(g, 0);
         wp.partial = e->wg_partial; wp.bias_partial = e->wg_bias_partial; wp.zero = e->zero_page;
-        err = e->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, e->math, s);
+        err = e->math == 3 ? launch_wgrad_s3(wp, s) : e->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, e->math, s);
         if (err == hipSuccess) {
             WgradReduceParams rp; memset(&rp, 0, sizeof(rp));
             rp.partial = e->wg_partial; rp.bias_partial = e->wg_bias_partial; rp.nparts = e->nparts; rp.n_in = n_in; rp.n_g = 1;

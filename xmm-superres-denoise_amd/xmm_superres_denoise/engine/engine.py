@@ -56,15 +56,16 @@ class Engine:
         except Exception:
             pass
 
-    MATH = {"fp32": 0, "bf16x3": 1, "bf16x3_p16": 2}
+    MATH = {"fp32": 0, "bf16x3": 1, "bf16x3_p16": 2, "bf16x6": 3}
 
     def set_math(self, mode: str):
-        """'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16 MFMA over fp32 planes) or 'bf16x3_p16' (split-bf16 MFMA over
-        pre-split P16 planes, LDS-DMA staging); include/xsd.h: xsd_set_math."""
+        """'fp32' (exact fp32 MFMA), 'bf16x6' (fp32-class: exact 3-term bf16 split, 6 products, single-rounding MFMA
+        accumulation, fp32 planes), 'bf16x3' (2-term split, 16-bit significands, fp32 planes) or 'bf16x3_p16' (2-term
+        split over pre-split P16 planes, LDS-DMA staging); include/xsd.h: xsd_set_math."""
         check(self.L.xsd_set_math(self.h, self.MATH[mode]))
 
     def get_math(self) -> str:
-        return {0: "fp32", 1: "bf16x3", 2: "bf16x3_p16"}[int(self.L.xsd_get_math(self.h))]
+        return {v: k for k, v in self.MATH.items()}[int(self.L.xsd_get_math(self.h))]
 
     # ---- weights
     def pack(self, flat_params: torch.Tensor):

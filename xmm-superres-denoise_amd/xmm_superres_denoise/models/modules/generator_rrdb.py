@@ -176,8 +176,8 @@ class _GeneratorRRDB(nn.Module):
         return self.flatten_parameters()
 
     def set_math(self, mode: str):
-        """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA with fp32 accumulation, ~5e-6 whole-net error)."""
-        if mode not in ("fp32", "bf16x3", "bf16x3_p16"):
+        """Math mode of the conv kernels (Engine.set_math): 'fp32', 'bf16x6' (fp32-class split), 'bf16x3', 'bf16x3_p16'."""
+        if mode not in Engine.MATH:
             raise ValueError(mode)
         self._math = mode
         if self._engine is not None:
