@@ -9,7 +9,7 @@ x = torch.rand(8,1,512,512,device='cuda')
 with torch.no_grad():
     for _ in range(3): m(x)
     torch.cuda.synchronize()
-    eng=m._engine; out=(ctypes.c_uint64*8)()
+    eng=m._engine; out=(ctypes.c_uint64*16)()
     eng.L.xsd_debug_stamps(eng.h,1,None)
     for _ in range(3): m(x)
     torch.cuda.synchronize()

@@ -10,7 +10,7 @@ x = torch.rand(B,1,512,512,device='cuda')
 with torch.no_grad():
     m(x); torch.cuda.synchronize()
     eng = m._engine
-    out = (ctypes.c_uint64*8)()
+    out = (ctypes.c_uint64*16)()
     eng.L.xsd_debug_stamps(eng.h, 1, None)
     t0=torch.cuda.Event(enable_timing=True); t1=torch.cuda.Event(enable_timing=True)
     t0.record(); m(x); t1.record(); torch.cuda.synchronize()

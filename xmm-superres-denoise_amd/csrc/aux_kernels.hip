@@ -386,46 +386,35 @@ __global__ void pack_weights_p16_kernel(const float* params, const PackDesc* des
     }
 }
 
-// math mode 3 panels (conv3x3_s3.hip, "bf16x6"): 16-bit elements [s2][tap][hi|mid|lo][lane = h*32 + m][j]; row m is the
-// output channel (input channel for the dgrad panels), the k index of element j is channel 16*s2 + 8h + j of the 32-channel
-// K-chunk.  hi + mid + lo == the fp32 weight exactly (round-to-nearest split).  27,648 elements (55,296 B) per panel.
-__global__ void pack_weights_s3_kernel(const float* params, const PackDesc* descs, unsigned short* fwd, unsigned short* bwd)
+// math mode 3 panels (conv3x3_s3.hip, "bf16x6"): fp32 in the fragment order of the bf16 MFMA, [s2][tap][lane = h*32 + m][j]:
+// row m is the output channel (input channel for the dgrad panels), the k index of element j is channel 16*s2 + 8h + j of
+// the 32-channel K-chunk.  The conv kernel splits them into three bf16 terms on the way into LDS (streaming 4 B instead of
+// 6 B per weight).  PANEL_FLOATS per panel, like the fp32 panels.
+__global__ void pack_weights_s3_kernel(const float* params, const PackDesc* descs, float* fwd, float* bwd)
 {
     const PackDesc d = descs[blockIdx.y];
     const int ns = d.cin / 32, nn = d.cout / 32;
-    const int PE = 2 * S3_PANEL_FLOATS; // 27,648 16-bit elements per panel
-    const long long total = (long long)ns * nn * PE;
+    const long long total = (long long)ns * nn * PANEL_FLOATS;
     const float* W = params + d.src_w;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        int r = (int)(e % PE);
-        const int panel = (int)(e / PE);
+        int r = (int)(e % PANEL_FLOATS);
+        const int panel = (int)(e / PANEL_FLOATS);
         const int j = r & 7; r >>= 3;
         const int m = r & 31; r >>= 5;
         const int h = r & 1; r >>= 1;
-        const int term = r % 3; r /= 3;
         const int tap = r % 9;
         const int s2 = r / 9;
         const int k = 16 * s2 + 8 * h + j;
-        float wf, wb;
         {
             const int n = panel / ns, s = panel % ns;
             const int oc = d.shuffle ? (4 * m + n) : (32 * n + m);
-            wf = W[((long long)oc * d.cin + 32 * s + k) * 9 + tap];
+            fwd[d.dst_fwd + e] = W[((long long)oc * d.cin + 32 * s + k) * 9 + tap];
         }
         {
             const int s = panel / nn, n = panel % nn;
             const int oc = d.shuffle ? (4 * k + n) : (32 * n + k);
-            wb = d.bwd_scale * W[((long long)oc * d.cin + 32 * s + m) * 9 + (8 - tap)];
+            bwd[d.dst_bwd + e] = d.bwd_scale * W[((long long)oc * d.cin + 32 * s + m) * 9 + (8 - tap)];
         }
-        auto term_of = [&](float w) {
-            const __bf16 t0 = (__bf16)w;
-            const float r1 = w - (float)t0;
-            const __bf16 t1 = (__bf16)r1;
-            const __bf16 t2 = (__bf16)(r1 - (float)t1);
-            return __builtin_bit_cast(unsigned short, term == 0 ? t0 : term == 1 ? t1 : t2);
-        };
-        fwd[3 * d.dst_fwd + e] = term_of(wf);   // dst_* count fp32 panel floats (9,216 per panel): x3 = 27,648 elements
-        bwd[3 * d.dst_bwd + e] = term_of(wb);
     }
 }
 
@@ -655,10 +644,10 @@ hipError_t launch_pack_weights_p16(const float* params, const PackDesc* descs_de
     hipLaunchKernelGGL(pack_weights_p16_kernel, dim3(72, ndesc), dim3(256), 0, s, params, descs_dev, fwd, bwd);
     return hipGetLastError();
 }
-hipError_t launch_pack_weights_s3(const float* params, const PackDesc* descs_dev, int ndesc, unsigned short* fwd,
-                                  unsigned short* bwd, hipStream_t s)
+hipError_t launch_pack_weights_s3(const float* params, const PackDesc* descs_dev, int ndesc, float* fwd, float* bwd,
+                                  hipStream_t s)
 {
-    hipLaunchKernelGGL(pack_weights_s3_kernel, dim3(108, ndesc), dim3(256), 0, s, params, descs_dev, fwd, bwd);
+    hipLaunchKernelGGL(pack_weights_s3_kernel, dim3(36, ndesc), dim3(256), 0, s, params, descs_dev, fwd, bwd);
     return hipGetLastError();
 }
 hipError_t launch_plane_convert(const float* in, float* out, long long npix, int to_p16, hipStream_t s)

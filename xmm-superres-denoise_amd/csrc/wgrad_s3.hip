@@ -18,6 +18,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) f32x4* gf32x4p;
 
 constexpr int W3_THREADS = 512;
 constexpr int W3_X_SLOTS = HALO_PX * 8;                               // 2720 (pixel, channel quad) slots
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradPara
 
     f32x4 px[W3_X_ROUNDS];
     f32x4 pg[W3_G_ROUNDS];
+    const float* zero = reinterpret_cast<const float*>(P.zero);
 
     auto load_tile = [&](int t) {
         const int tx = t % P.tilesX;
@@ -100,9 +102,9 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradPara
             const int hy = p / HALO_W, hx = p - hy * HALO_W;
             const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
             const bool ok = (slot < W3_X_SLOTS) && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(xb + (long long)gy * xp.rs + gx * xp.ps + c * 4);
-            px[r] = v;
+            // unconditional load (padding reads the zero page): a branch around it would make hipcc wait for the whole
+            // prefetch at the join, i.e. BEFORE the MFMAs it is meant to overlap
+            px[r] = *(gf32x4p)(ok ? xb + (long long)gy * xp.rs + gx * xp.ps + c * 4 : zero);
         }
 #pragma unroll
         for (int r = 0; r < W3_G_ROUNDS; ++r) {
@@ -110,9 +112,7 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradPara
             const int p = slot >> 3, c = slot & 7;
             const int gy = y0 + (p >> 5), gx = x0 + (p & 31);
             const bool ok = gy < P.H && gx < P.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(gb + (long long)gy * gp.rs + gx * gp.ps + c * 4);
-            pg[r] = v;
+            pg[r] = *(gf32x4p)(ok ? gb + (long long)gy * gp.rs + gx * gp.ps + c * 4 : zero);
         }
     };
     auto store_tile = [&]() {
@@ -146,16 +146,26 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradPara
     const char* xbase = smem + wv * (HALO_W * 64) + lane_off; // + term image + ((dy*34 + dx + 16*mf) * 64)
     const char* gbase = smem + W3_G_OFF + wv * (TILE_W * 64) + lane_off;
 
+#ifdef XSD_DIAG   // phase stamps (diagnostic library variant only; tools/stamps_train.py)
+    unsigned long long st[5] = {0, 0, 0, 0, 0}, ntile = 0;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    const bool stamp = P.dbg != nullptr;
+#define W3_TICK(i) do { if (stamp) { const unsigned long long t_ = __builtin_readcyclecounter(); st[i] += t_ - t0; t0 = t_; } } while (0)
+#else
+#define W3_TICK(i) do { } while (0)
+#endif
     int t = part;
     if (t < ntiles) {
         load_tile(t);
         store_tile();
     }
     __syncthreads();
+    W3_TICK(0);
 #pragma unroll 1
     for (; t < ntiles; t += P.nparts) {
         const bool more = (t + P.nparts < ntiles);
         if (more) load_tile(t + P.nparts);
+        W3_TICK(0);
         // Running accumulators take every product: 12 roundings per tile row and tap, against 32 for an fp32 fma chain over
         // the same 32 pixels (single-layer error vs float64: tools/dbg_layer.py).
         bf16x8 g[2][3];
@@ -180,10 +190,24 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradPara
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, g[mf][0], acc[tap], 0, 0, 0);
             }
         }
+        W3_TICK(1);
         __syncthreads();
+        W3_TICK(2);
         if (more) store_tile();
+        W3_TICK(3);
         __syncthreads();
+        W3_TICK(4);
+#ifdef XSD_DIAG
+        ++ntile;
+#endif
     }
+#ifdef XSD_DIAG
+    if (stamp && tid == 0) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) atomicAdd(&P.dbg[8 + q], st[q]);
+        atomicAdd(&P.dbg[13], ntile);
+    }
+#endif
 
     // ---- cross-wave reduction through LDS, one tap at a time (8 waves x 4 KiB), then one coalesced store per tap
     float* red = reinterpret_cast<float*>(smem);
@@ -226,6 +250,7 @@ hipError_t launch_wgrad_s3(const WgradParams& p, hipStream_t stream)
         if (e != hipSuccess) return e;
         done = true;
     }
+    if (!p.zero) return hipErrorInvalidValue;
     const dim3 g(p.nparts, p.n_in, p.n_g), b(W3_THREADS);
     hipLaunchKernelGGL(wgrad_s3_kernel, g, b, W3_LDS_BYTES, stream, p);
     return hipGetLastError();

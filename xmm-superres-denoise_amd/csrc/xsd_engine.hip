@@ -35,9 +35,6 @@ float debug_residency_ms(int grid, int threads, int lds_bytes, int us);
 hipError_t launch_pack_shuffle_bias(const float* b, float* out, hipStream_t s);
 }
 
-static inline long long panel_floats(int math) { return math == 3 ? S3_PANEL_FLOATS : PANEL_FLOATS; }
-static inline long long panel_off(int math, long long off) { return off / PANEL_FLOATS * panel_floats(math); }
-
 static thread_local std::string g_err;
 static int fail(int code, const char* fmt, ...)
 {
@@ -112,7 +109,7 @@ struct xsd_engine {
     const float* b_dy = nullptr;
     float* b_dx = nullptr;
     float* b_grads = nullptr;
-    void* zero_page = nullptr;         // 256 B of zeros (math mode 2 DMA source for padding)
+    void* zero_page = nullptr;         // 256 B of zeros (padding source of the DMA / unconditional loads) + 256 B of trash
     unsigned long long* dbg = nullptr; // conv phase stamps (diagnostic)
     // profiling
     bool prof = false;
@@ -183,14 +180,14 @@ struct Builder {
         freelist[level].push_back(reinterpret_cast<uintptr_t>(p) - base);
     }
 
-    // packed-panel pointers; `off` counts fp32-panel floats (PANEL_FLOATS per panel), mode 3 panels are 1.5x as large
+    // packed-panel pointers (every mode's panels are PANEL_FLOATS * 4 bytes)
     const float* fwdp(long long off) const
     {
-        return e->math ? reinterpret_cast<const float*>(e->pk_fwd_s) + panel_off(e->math, off) : e->pk_fwd + off;
+        return e->math ? reinterpret_cast<const float*>(e->pk_fwd_s) + off : e->pk_fwd + off;
     }
     const float* bwdp(long long off) const
     {
-        return e->math ? reinterpret_cast<const float*>(e->pk_bwd_s) + panel_off(e->math, off) : e->pk_bwd + off;
+        return e->math ? reinterpret_cast<const float*>(e->pk_bwd_s) + off : e->pk_bwd + off;
     }
     ConvParams conv_base(int level) const
     {
@@ -248,7 +245,7 @@ struct Builder {
         ConvParams p = p_in;
         {
             const int nst = p.n_out > 1 ? p.n_out : p.n_in;
-            for (int i = 0; i < nst; ++i) if (!p.wstep[i]) p.wstep[i] = p.wpanel + (long long)i * panel_floats(e->math);
+            for (int i = 0; i < nst; ++i) if (!p.wstep[i]) p.wstep[i] = p.wpanel + (long long)i * PANEL_FLOATS;
         }
         xsd_engine* eng = e;
         const double px = (double)p.B * p.H * p.W;
@@ -286,7 +283,7 @@ struct Builder {
             wp.partial = eng->wg_partial; wp.bias_partial = eng->wg_bias_partial;
             rp.partial = eng->wg_partial; rp.bias_partial = eng->wg_bias_partial;
             rp.dw = eng->b_grads + w_off; rp.db = eng->b_grads + b_off;
-            wp.zero = eng->zero_page; wp.ablate = eng->ablate; rp.p16 = eng->math == 2;
+            wp.zero = eng->zero_page; wp.ablate = eng->ablate; wp.dbg = eng->dbg; rp.p16 = eng->math == 2;
             hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return eng->math == 3 ? launch_wgrad_s3(wp, s) : eng->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, eng->math, s); });
             if (err != hipSuccess) return err;
             return launch_wgrad_reduce(rp, s);
@@ -614,10 +611,10 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
 #define CK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { int rc = fail(XSD_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); xsd_destroy(e); return rc; } } while (0)
     CK(hipMalloc((void**)&e->pk_fwd, sizeof(float) * pk));
     CK(hipMalloc((void**)&e->pk_bwd, sizeof(float) * pk));
-    CK(hipMalloc((void**)&e->pk_fwd_s, sizeof(float) * panel_off(3, pk)));   // sized for the largest (mode 3) panels
-    CK(hipMalloc((void**)&e->pk_bwd_s, sizeof(float) * panel_off(3, pk)));
-    CK(hipMalloc((void**)&e->zero_page, 256));
-    CK(hipMemset(e->zero_page, 0, 256));
+    CK(hipMalloc((void**)&e->pk_fwd_s, sizeof(float) * pk));
+    CK(hipMalloc((void**)&e->pk_bwd_s, sizeof(float) * pk));
+    CK(hipMalloc((void**)&e->zero_page, 512));   // [0,256): zeros (padding source); [256,512): trash (stores of lanes outside the image)
+    CK(hipMemset(e->zero_page, 0, 512));
     CK(hipMalloc((void**)&e->pk_edge, sizeof(float) * 4 * 288));
     CK(hipMalloc((void**)&e->pk_sbias, sizeof(float) * (sb ? sb : 1)));
     CK(hipMalloc((void**)&e->descs_dev, sizeof(PackDesc) * descs.size()));
@@ -658,7 +655,7 @@ int xsd_pack_weights(xsd_engine* e, const float* dev_params, void* stream)
     hipStream_t s = (hipStream_t)stream;
     e->params = dev_params;
     if (e->math == 3)
-        HIPCHK(launch_pack_weights_s3(dev_params, e->descs_dev, e->ndesc, e->pk_fwd_s, e->pk_bwd_s, s));
+        HIPCHK(launch_pack_weights_s3(dev_params, e->descs_dev, e->ndesc, reinterpret_cast<float*>(e->pk_fwd_s), reinterpret_cast<float*>(e->pk_bwd_s), s));
     else if (e->math == 2)
         HIPCHK(launch_pack_weights_p16(dev_params, e->descs_dev, e->ndesc, e->pk_fwd_s, e->pk_bwd_s, s));
     else if (e->math == 1)
@@ -840,14 +837,14 @@ int xsd_debug_occupancy(int lds_bytes) { return xsd::debug_conv_occupancy(lds_by
 float xsd_debug_residency_ms(int grid, int threads, int lds_bytes, int us) { return xsd::debug_residency_ms(grid, threads, lds_bytes, us); }
 
 // diagnostic: accumulate shader-cycle stamps of the conv kernel's phases (enable != 0 allocates/zeroes; read copies out)
-int xsd_debug_stamps(xsd_engine* e, int enable, unsigned long long* out8)
+int xsd_debug_stamps(xsd_engine* e, int enable, unsigned long long* out16)
 {
     if (!e) return fail(XSD_ERR_ARG, "null engine");
     HIPCHK(hipDeviceSynchronize());
-    if (out8 && e->dbg) HIPCHK(hipMemcpy(out8, e->dbg, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (out16 && e->dbg) HIPCHK(hipMemcpy(out16, e->dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (enable) {
-        if (!e->dbg) HIPCHK(hipMalloc((void**)&e->dbg, 8 * sizeof(unsigned long long)));
-        HIPCHK(hipMemset(e->dbg, 0, 8 * sizeof(unsigned long long)));
+        if (!e->dbg) HIPCHK(hipMalloc((void**)&e->dbg, 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(e->dbg, 0, 16 * sizeof(unsigned long long)));
     } else if (e->dbg) { hipFree(e->dbg); e->dbg = nullptr; }
     return XSD_OK;
 }
@@ -881,14 +878,14 @@ int xsd_profile_read(xsd_engine* e, int klass, double* total_ms, int64_t* launch
 // ---- single-layer test hooks ---------------------------------------------------------------------------------
 static int pack_single(const float* dev_w, int cout, int cin, float** fwd, float** bwd, int math, hipStream_t s)
 {
-    const long long n = (long long)(cout / 32) * (cin / 32) * panel_floats(math);
+    const long long n = (long long)(cout / 32) * (cin / 32) * PANEL_FLOATS;
     PackDesc d; d.src_w = 0; d.dst_fwd = 0; d.dst_bwd = 0; d.cout = cout; d.cin = cin; d.shuffle = 0; d.bwd_scale = 1.f;
     PackDesc* dd = nullptr;
     HIPCHK(hipMalloc((void**)fwd, sizeof(float) * n));
     HIPCHK(hipMalloc((void**)bwd, sizeof(float) * n));
     HIPCHK(hipMalloc((void**)&dd, sizeof(PackDesc)));
     HIPCHK(hipMemcpy(dd, &d, sizeof(d), hipMemcpyHostToDevice));
-    if (math == 3) HIPCHK(launch_pack_weights_s3(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
+    if (math == 3) HIPCHK(launch_pack_weights_s3(dev_w, dd, 1, *fwd, *bwd, s));
     else if (math == 2) HIPCHK(launch_pack_weights_p16(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
     else if (math == 1) HIPCHK(launch_pack_weights_split(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
     else HIPCHK(launch_pack_weights(dev_w, dd, 1, *fwd, *bwd, s));
@@ -907,7 +904,7 @@ struct TmpPlanes {
 static hipError_t run_conv(xsd_engine* e, ConvParams& p, hipStream_t s)
 {
     p.zero = e->zero_page;
-    for (int i = 0; i < (p.n_out > 1 ? p.n_out : p.n_in); ++i) p.wstep[i] = p.wpanel + (long long)i * panel_floats(e->math);
+    for (int i = 0; i < (p.n_out > 1 ? p.n_out : p.n_in); ++i) p.wstep[i] = p.wpanel + (long long)i * PANEL_FLOATS;
     if (e->math == 3) return launch_conv3x3_s3(p, s);
     if (e->math == 2) return (e->p16v2 && p.n_out == 1) ? launch_conv3x3_p16v2(p, e->p16v2 == 2, s) : launch_conv3x3_p16(p, s);
     return e->big ? launch_conv3x3_big(p, e->math, s) : launch_conv3x3_mfma(p, e->math, s);

@@ -18,10 +18,8 @@ constexpr int IN_LDS_BYTES = HALO_PX * 128;     // 43,520  (XOR-swizzled 16-B ch
 constexpr int PANEL_FLOATS = 9 * 32 * 32;       // 9,216 floats per (K-chunk x N-chunk) weight panel
 constexpr int W_LDS_BYTES = PANEL_FLOATS * 4;   // 36,864
 constexpr int CONV_LDS_BYTES = IN_LDS_BYTES + W_LDS_BYTES; // 80,384 -> 2 workgroups per CU (160 KiB LDS)
-// math mode 3 (bf16x6, conv3x3_s3.hip): weights pre-split into three bf16 terms, one panel = two 16-channel half-panels
-// [s2][tap][hi|mid|lo][64 lanes][8 bf16]
-constexpr int S3_WH_BYTES = 9 * 3 * 1024;           // 27,648 per half-panel
-constexpr int S3_PANEL_FLOATS = 2 * S3_WH_BYTES / 4; // 13,824 floats (55,296 B) per (K-chunk x N-chunk) panel
+// math mode 3 (bf16x6, conv3x3_s3.hip): a weight half-panel in LDS, split into three bf16 terms: [tap][hi|mid|lo][64 lanes][8 bf16]
+constexpr int S3_WH_BYTES = 9 * 3 * 1024;           // 27,648
 
 // input plane reference with general strides (pixel-shuffled reads use rs = 2*Whr*32, ps = 64)
 struct PlaneIn {
@@ -87,6 +85,7 @@ struct WgradParams {
     const void* zero;    // zero page (P16 kernel)
     int ablate;          // diagnostic (env XSD_ABLATE): 4096 = request the G tile only for the first tile of a workgroup
     int pad_;
+    unsigned long long* dbg; // diagnostic phase stamps (null in production): slots [8..15] of the engine's stamp buffer
 };
 
 struct WgradReduceParams {
