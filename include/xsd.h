@@ -67,8 +67,8 @@ int64_t xsd_param_count(const xsd_engine* e);
  * products and the fp32 accumulator exactly and rounds once, so against float64 this mode is at least as accurate as
  * mode 0 and as the reference's fp32 nn.Conv2d (tests/test_hip_precision.py).  Planes stay fp32.
  * Modes 0 and 3 carry the reference's fp32 precision; modes 1 and 2 carry 16-bit significands (tolerance-only parity).
- * Default from the environment variable XSD_MATH ("fp32" | "bf16x6" | "bf16x3" | "bf16x3_p16").  Changing it invalidates
- * the packed weights and the plan. */
+ * Default: 3 (bf16x6), or the environment variable XSD_MATH ("fp32" | "bf16x6" | "bf16x3" | "bf16x3_p16").  Changing it
+ * invalidates the packed weights and the plan. */
 int xsd_set_math(xsd_engine* e, int mode);
 int xsd_get_math(const xsd_engine* e);
 

@@ -92,3 +92,15 @@ def test_no_product_import_of_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "oracle" not in txt.lower() or f == "README.md", os.path.join(dp, f)
+
+
+def test_constructor_rejects_unsupported_widths_early():
+    """reference constructors take any widths (generator_rrdb.py:10-54); the engine is specialised, and says so at
+    construction instead of at the first forward"""
+    from xmm_superres_denoise import models as M
+    with pytest.raises(ValueError, match="num_filters = 32"):
+        M.GeneratorRRDB_DN(1, 1, 8, 1)
+    with pytest.raises(ValueError, match="in_channels"):
+        M.GeneratorRRDB_SR(3, 1, 32, 1)
+    with pytest.raises(ValueError, match="num_upsample"):
+        M.GeneratorRRDB_SR(1, 1, 32, 1, num_upsample=3)

@@ -1,0 +1,105 @@
+"""BASELINE.json's single-GPU workloads at their full sizes, under assertions (the oracle is far too slow here, so these
+are size-independent properties):
+  configs[1]  SR 2x forward, batch 16, 1x512x512 -> 1x1024x1024
+  configs[2]  DN train step, batch 32 (L1 + Adam) -- also with the reference's shipped loss (0.5 PSNR + 0.5 MS-SSIM)
+  configs[3]/[4] per-GPU share: SR train step, and a DN train step fed by the on-GPU input pipeline
+              (int32 counts -> detector mask -> pad -> sqrt-normalize) as `bench.py --input-pipeline` does.
+Properties: bitwise determinism, batch independence (a tile's output does not depend on its neighbours), agreement of the
+fp32-class math modes, outputs inside [0,1], finite and reproducible gradients, the workspace fits, the update moves."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gen_common as gc
+from util_hip import G, build_module
+
+pytestmark = pytest.mark.gpu
+
+HEADLINE = "bf16x6"
+
+
+def _tiles(shape, seed):
+    return torch.from_numpy(gc.make_input(shape, seed)).cuda()
+
+
+def test_sr_forward_batch16_full_size():
+    state = gc.make_state("sr", 32, 4, 3101, last_bias=0.05)
+    x = _tiles((16, 1, 512, 512), 3102)
+    m = build_module("sr", 4, 1, state).set_math(HEADLINE)
+    with torch.no_grad():
+        y1 = m(x)
+        y2 = m(x)
+        y_one = m(x[5:6].contiguous())
+    assert y1.shape == (16, 1, 1024, 1024)
+    assert torch.equal(y1, y2)                                  # determinism
+    assert torch.equal(y1[5:6], y_one)                          # batch independence
+    assert float(y1.min()) >= 0.0 and float(y1.max()) <= 1.0 and torch.isfinite(y1).all()
+    assert float(y1.std()) > 1e-3                               # not a constant image
+    m32 = build_module("sr", 4, 1, state).set_math("fp32")
+    with torch.no_grad():
+        y32 = m32(x[:2].contiguous())
+    assert float((y1[:2] - y32).abs().max()) < 5e-6             # the two fp32-class modes agree to a few ulp of 1.0
+
+
+def _train_step_properties(kind, batch, loss=None, steps=2):
+    from xmm_superres_denoise.parallel import DataParallelTrainer
+    s = 2 if kind == "sr" else 1
+    state = gc.make_state(kind, 32, 4, 3201, last_bias=0.05 if kind == "sr" else None)
+    x = _tiles((batch, 1, 512, 512), 3202)
+    t = _tiles((batch, 1, 512 * s, 512 * s), 3203)
+    runs = []
+    for _ in range(2):      # the same two steps twice from the same start: bitwise reproducible
+        m = build_module(kind, 4, 1, state).set_math(HEADLINE)
+        tr = DataParallelTrainer(m, lr=1e-4, loss=loss)
+        losses = [float(tr.train_step(x, t)) for _ in range(steps)]
+        runs.append((losses, tr.grads.clone(), tr.flat.clone()))
+        del tr, m
+        torch.cuda.empty_cache()
+    (l1, g1, p1), (l2, g2, p2) = runs
+    assert l1 == l2 and torch.equal(g1, g2) and torch.equal(p1, p2)
+    assert all(np.isfinite(l1)) and torch.isfinite(g1).all() and torch.isfinite(p1).all()
+    start = np.concatenate([v.ravel() for v in state.values()])
+    moved = np.abs(p1.cpu().numpy() - start)
+    assert moved.max() > 5e-5 and moved.max() < 2.5e-4 * steps      # Adam: |update| <= lr per step
+    assert float(g1.abs().max()) > 0
+    return l1
+
+
+def test_dn_train_batch32_full_size():
+    losses = _train_step_properties("dn", 32)
+    assert losses[1] < losses[0] + 1e-4
+
+
+def test_sr_train_batch32_full_size():
+    _train_step_properties("sr", 32)
+
+
+def test_dn_train_paper_loss_full_size():
+    """the reference's shipped training loss (utils/loss_functions.py:11-47 with res/configs/loss_functions.toml, 'linear')"""
+    from xmm_superres_denoise.utils import create_loss, load_loss_config
+    _train_step_properties("dn", 16, loss=create_loss(*load_loss_config("linear")))
+
+
+def test_input_pipeline_train_step_full_size():
+    """configs[4]: every step starts from int32 count tiles (411 x 403) and runs detector-mask * pad * sqrt-normalize on the
+    GPU; the composed tile equals mask_pad_normalize of the same counts bit for bit, and the step trains."""
+    from xmm_superres_denoise.engine import compose_input, mask_pad_normalize
+    from xmm_superres_denoise.parallel import DataParallelTrainer
+    B = 16
+    z = np.load(os.path.join(G, "example_data.npz"))
+    m1 = np.unpackbits(z["mask1x_bits"])[: int(np.prod(z["mask1x_shape"]))].reshape(z["mask1x_shape"])
+    mask = torch.from_numpy(m1).cuda()
+    counts = torch.from_numpy(np.random.default_rng(2).poisson(0.1, size=(B, 411, 403)).astype(np.int32)).cuda()
+    xin = compose_input(counts, None, None, mask, 512, 0.0022336, "sqrt")
+    assert torch.equal(xin, mask_pad_normalize(counts, mask, 512, 0.0022336, "sqrt"))
+    assert xin.shape == (B, 1, 512, 512) and float(xin.min()) >= 0 and float(xin.max()) <= 1
+    inside = xin[:, :, 50:461, 54:457]           # 411 x 403 centred in 512 x 512: top 50, left 54
+    assert float(xin.sum()) == float(inside.sum())          # everything outside the detector frame is padding
+    m = build_module("dn", 4, 1, gc.make_state("dn", 32, 4, 3301)).set_math(HEADLINE)
+    tr = DataParallelTrainer(m, lr=1e-4)
+    t = _tiles((B, 1, 512, 512), 3302)
+    l0 = float(tr.train_step(compose_input(counts, None, None, mask, 512, 0.0022336, "sqrt"), t))
+    l1 = float(tr.train_step(compose_input(counts, None, None, mask, 512, 0.0022336, "sqrt"), t))
+    assert np.isfinite([l0, l1]).all() and l1 < l0 + 1e-4

@@ -13,16 +13,11 @@ from util_hip import nchw_to_planes, planes_to_nchw, ptr_array
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["fp32-small", "bf16x6-small", "bf16x3-small", "fp32-big", "bf16x3-big", "bf16x3_p16-small", "bf16x3_p16-v2", "bf16x3_p16-v3"])
+@pytest.fixture(scope="module", params=["fp32", "bf16x6", "bf16x3", "bf16x3_p16"])
 def eng(request):
-    import os
     from xmm_superres_denoise.engine import Engine
-    math, conv = request.param.split("-")
-    os.environ["XSD_CONV"] = conv          # conv structure is chosen at engine creation (8x32 tiles vs 16x32 + DMA ring)
-    os.environ["XSD_P16"] = conv           # "v2" = role-split P16 K-loop kernel
+    math = request.param
     e = Engine("dn", 1, 1, 32, 1)
-    os.environ.pop("XSD_CONV")
-    os.environ.pop("XSD_P16")
     e.set_math(math)
     e.tol = {"fp32": 2e-5, "bf16x6": 2e-5, "bf16x3": 6e-5, "bf16x3_p16": 1e-4}[math]   # bf16x3: <= 3*2^-16 per product, random-sign sums
     return e

@@ -9,7 +9,7 @@ import torch
 
 import gen_common as gc
 from oracle import oracle
-from util_hip import G, assert_grad_close, build_module, load_case
+from util_hip import FLIP_LOG, G, assert_grad_close, build_module, flip_candidates, load_case
 
 pytestmark = pytest.mark.gpu
 
@@ -22,11 +22,20 @@ def _relmax(a, b):
 
 
 MATHS = ["fp32", "bf16x6", "bf16x3", "bf16x3_p16"]
-# gradient tolerances (see util_hip.assert_grad_close): exact-fp32 MFMA vs split-bf16 MFMA (3 x 2^-16 per product)
+FP32_CLASS = ("fp32", "bf16x6")   # held to the flip-aware comparison: only rows named by a flip candidate may deviate
+# gradient tolerances (see util_hip.assert_grad_close).  fp32-class modes: 2e-4 of the tensor's largest entry on every row
+# that has no flip candidate (north_star: 1e-3).  The 16-bit modes (hi+lo bf16 significands; extras, never the headline)
+# are tolerance-only: 3 x 2^-16 per product, P16 additionally rounds every stored activation / gradient plane to 16 bits,
+# which is why its input-gradient (it passes through every layer's gradient plane) gets 5e-3.
 TIGHT = {"fp32": 2e-4, "bf16x6": 2e-4, "bf16x3": 5e-4, "bf16x3_p16": 1e-3}
-# input-gradient (dx) tolerance: dx is tiny for SR (it passes through every layer) and, in P16 mode, through gradient
-# planes that carry 16 significant bits
 DX_TIGHT = {"fp32": 4e-4, "bf16x6": 4e-4, "bf16x3": 1e-3, "bf16x3_p16": 5e-3}
+
+
+def _report_flips(tag, before):
+    recs = FLIP_LOG[before:]
+    if recs:
+        print(f"[flip report] {tag}: " + "; ".join(f"{r['tensor']}: {r['rows_over_tight']} rows over tight, {r['candidate_rows']} candidate rows, "
+                                                   f"{r['unexplained']} unexplained (max {r['max_rel_err']:.1e})" for r in recs))
 
 
 @pytest.mark.parametrize("math", MATHS)
@@ -40,7 +49,10 @@ def test_golden_forward_backward(name, kind, math):
     loss = torch.nn.functional.l1_loss(y, torch.from_numpy(t).cuda())
     assert abs(loss.item() - float(z["loss"][0])) < 1e-5
     loss.backward()
-    assert_grad_close(xd.grad.cpu().numpy().reshape(-1, x.shape[-1]), z["dx"].reshape(-1, x.shape[-1]), "dx", tight=DX_TIGHT[math], loose=5e-2, max_flip_frac=0.3)
+    cand, n_out = flip_candidates(kind, blocks, state, x, t, nup) if math in FP32_CLASS else (None, 0)
+    mark = len(FLIP_LOG)
+    assert_grad_close(xd.grad.cpu().numpy().reshape(-1, x.shape[-1]), z["dx"].reshape(-1, x.shape[-1]), "dx", tight=DX_TIGHT[math], loose=5e-2, max_flip_frac=0.3,
+                      candidates=cand, n_out_candidates=n_out)
     names = [str(n) for n in z["param_names"]]
     params = dict(m.named_parameters())
     assert list(params.keys()) == names
@@ -50,7 +62,8 @@ def test_golden_forward_backward(name, kind, math):
         assert abs(np.abs(g).sum() - a_ref) <= 1e-2 * a_ref + 1e-9, n
         assert abs(g.sum() - s_ref) <= 1e-2 * a_ref + 1e-9, n
         if "grad." + n in z.files:
-            assert_grad_close(g, z["grad." + n], n, tight=TIGHT[math])
+            assert_grad_close(g, z["grad." + n], n, tight=TIGHT[math], candidates=cand, n_out_candidates=n_out)
+    _report_flips(f"{name} {math}", mark)
 
 
 def test_forward_no_grad_matches_train_forward_and_reuses_planes():
@@ -80,14 +93,18 @@ def test_fresh_inputs_vs_oracle(kind, shape, nup, math):
     dx = eng.backward(dy, grads, need_dx=True)
     assert np.abs(y.cpu().numpy() - yo).max() < 1e-4
     assert abs(loss.item() - lo) < 1e-5
-    assert_grad_close(dx.cpu().numpy().reshape(-1, dxo.shape[-1]), dxo.reshape(-1, dxo.shape[-1]), "dx", tight=DX_TIGHT[math], loose=5e-2, max_flip_frac=0.3)
+    cand, n_out = flip_candidates(kind, 2, state, x, t, nup) if math in FP32_CLASS else (None, 0)
+    mark = len(FLIP_LOG)
+    assert_grad_close(dx.cpu().numpy().reshape(-1, dxo.shape[-1]), dxo.reshape(-1, dxo.shape[-1]), "dx", tight=DX_TIGHT[math], loose=5e-2, max_flip_frac=0.3,
+                      candidates=cand, n_out_candidates=n_out)
     g = grads.cpu().numpy()
     shapes = gc.rrdb_param_shapes(kind, 32, 2, num_upsample=nup)
     off = 0
     for n, shp in shapes.items():
         k = int(np.prod(shp))
-        assert_grad_close(g[off:off + k].reshape(shp), go[off:off + k].reshape(shp), n, tight=TIGHT[math])
+        assert_grad_close(g[off:off + k].reshape(shp), go[off:off + k].reshape(shp), n, tight=TIGHT[math], candidates=cand, n_out_candidates=n_out)
         off += k
+    _report_flips(f"{kind}{shape} nup={nup} {math}", mark)
 
 
 def test_staged_backward_equals_monolithic():

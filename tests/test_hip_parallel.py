@@ -47,7 +47,7 @@ def _launch(out_dir, world, backend, steps, math):
     return [np.load(os.path.join(out_dir, f"rank{r}.npz")) for r in range(world)]
 
 
-@pytest.mark.parametrize("math", ["fp32"])
+@pytest.mark.parametrize("math", ["bf16x6", "fp32"])
 def test_two_ranks_on_hip_engine_match_single_process_full_batch(tmp_path, math):
     import dp_worker as W
     from xmm_superres_denoise.parallel import DataParallelTrainer

@@ -114,3 +114,38 @@ def test_dp2_matches_single_process():
     assert np.abs(p0 - tr.flat.numpy()).max() < 2e-6
     start = np.concatenate([v.ravel() for v in gc.make_state("dn", 32, 1, 300).values()])
     assert np.abs(p0 - start).max() > 1e-4  # it actually trained
+
+
+def _metric_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xmm_superres_denoise.utils.loss_functions import EpochState
+    st = EpochState()
+    # out vector of xsd_loss_eval: [total, l1, poisson, psnr, ssim, ms_ssim, mse, tmin, tmax]
+    outs = [[0, 0.10, 0.5, 0, 0.80, 0.70, 0.005, 0.10, 0.60], [0, 0.30, 0.7, 0, 0.60, 0.50, 0.080, 0.05, 0.90]]
+    st.add(torch.tensor(outs[rank], dtype=torch.float32), n=1000 * (rank + 1), nimg=2 * (rank + 1))
+    st.sync()
+    ret[rank] = {k: float(v) for k, v in st.compute().items()}
+    dist.destroy_process_group()
+
+
+def test_epoch_metric_states_are_reduced_not_averaged():
+    """Multi-rank validation metrics: the STATES are summed / min-maxed over ranks before compute(), like torchmetrics'
+    dist_reduce_fx (reference metrics/metrics.py:16-21).  PSNR of the pooled error differs from the mean of rank PSNRs."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_metric_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret[0] == ret[1]
+    sse = 0.005 * 1000 + 0.080 * 2000
+    mse = sse / 3000
+    dr = 0.90 - 0.0                       # running min starts at 0 (PeakSignalNoiseRatio(data_range=None))
+    want = {"psnr": 10 * np.log10(dr * dr / mse), "l2": mse, "l1": (0.10 * 1000 + 0.30 * 2000) / 3000,
+            "ssim": (0.80 * 2 + 0.60 * 4) / 6, "ms_ssim": (0.70 * 2 + 0.50 * 4) / 6, "poisson": (0.5 * 2 + 0.7 * 4) / 6}
+    for k, v in want.items():
+        assert abs(ret[0][k] - v) < 1e-6, (k, ret[0][k], v)
+    mean_of_rank_psnr = 0.5 * (10 * np.log10(0.6 ** 2 / 0.005) + 10 * np.log10(0.9 ** 2 / 0.080))
+    assert abs(ret[0]["psnr"] - mean_of_rank_psnr) > 0.1

@@ -49,14 +49,68 @@ def ptr_array(tensors):
     return arr
 
 
-def assert_grad_close(g, ref, name, tight=2e-4, loose=2e-2, max_flip_frac=0.15):
-    """Gradient comparison that is robust to the network's genuine discontinuities.
+def flip_candidates(kind, blocks, state, x, t, nup=1, eps=4e-6):
+    """Where can two fp32-accurate implementations legitimately take different branches of the network's step functions?
+    A float64 evaluation of the reference graph (rrdb_blocks.py:37-54, generator_rrdb.py:66-137) records, for every conv
+    that feeds a LeakyReLU, the output channels that hold a pre-activation within eps * rms(plane) of zero, plus whether any
+    output pixel sits within eps of a clamp bound or of its target (clamp mask, sign(y - t) of the L1 loss).
+    Returns ({param prefix: set(channels)}, n_output_candidates)."""
+    import torch.nn.functional as F
+    st = {k: torch.from_numpy(v).double() for k, v in state.items()}
+    cand = {}
 
-    LeakyReLU', the clamp mask and sign(y - t) are step functions: an activation within ~1e-6 of zero can take a
-    different branch in two fp32-accurate implementations, which changes ONE (pixel, channel) term and therefore one
-    output-channel row of one conv's dW/db by O(1/sqrt(N)), plus a tiny ripple upstream.  So: either every element
-    agrees to `tight` (relative to the tensor's max), or at most `max_flip_frac` of the leading-dimension rows exceed
-    `tight`, nothing exceeds `loose`, and the relative L2 error stays below `loose`/2."""
+    def conv(name, inp):
+        return F.conv2d(inp, st[name + ".weight"], st[name + ".bias"], padding=1)
+
+    def act(name, pre, slope):
+        rms = pre.pow(2).mean().sqrt()
+        near = (pre.abs() < eps * rms).any(dim=0).any(dim=-1).any(dim=-1)      # per output channel
+        ch = set(int(c) for c in torch.nonzero(near).flatten())
+        if ch:
+            cand[name] = ch
+        return F.leaky_relu(pre, slope)
+
+    xt = torch.from_numpy(x).double()
+    fea = conv("conv_first", xt)
+    cur = fea
+    for i in range(blocks):
+        rin = cur
+        for r in (1, 2, 3):
+            pre = f"rrdb.{i}.RDB{r}."
+            xs = [cur]
+            for c in (1, 2, 3, 4):
+                xs.append(act(pre + f"conv{c}", conv(pre + f"conv{c}", torch.cat(xs, 1)), 0.2))
+            cur = conv(pre + "conv5", torch.cat(xs, 1)) * 0.2 + cur
+        cur = cur * 0.2 + rin
+    fea = fea + conv("trunk_conv", cur)
+    if kind == "sr":
+        for u in range(nup):
+            fea = F.pixel_shuffle(act(f"upsampling.{3 * u}", conv(f"upsampling.{3 * u}", fea), 0.01), 2)
+        out = conv("conv_last", act("HRconv", conv("HRconv", fea), 0.2))
+    else:
+        out = conv("conv_last", fea) + xt
+    tt = torch.from_numpy(t).double()
+    y = out.clamp(0, 1)
+    n_out = int(((out.abs() < eps) | ((out - 1).abs() < eps) | ((y - tt).abs() < eps)).sum())
+    return cand, n_out
+
+
+FLIP_LOG = []     # one record per (case, tensor) that needed the flip allowance: printed by the tests, asserted to stay explainable
+
+
+def assert_grad_close(g, ref, name, tight=2e-4, loose=2e-2, max_flip_frac=0.15, candidates=None, n_out_candidates=0,
+                      strict=1e-3):
+    """Gradient comparison, relative to the tensor's largest entry.
+
+    LeakyReLU', the clamp mask and sign(y - t) are step functions: an activation within ~1e-6 of zero can take a different
+    branch in two fp32-accurate implementations.  That changes ONE (pixel, channel) term, i.e. the weight / bias gradient
+    ROW of that output channel of that conv by O(1/sqrt(N)), and sends a ripple well below 1e-3 upstream.
+      * `candidates` given (flip-aware mode, used for the fp32-class math modes): only the rows named by
+        flip_candidates() for this tensor may exceed `tight` (up to `loose`); every other row must agree to `tight`, and
+        nothing anywhere may exceed north_star's 1e-3 (`strict`) unless it is a candidate row.  With no candidate for the
+        tensor (and no output-pixel candidate upstream of everything) ANY excess fails.
+      * `candidates` None (16-bit tolerance-only modes): at most `max_flip_frac` of the rows may exceed `tight`, none
+        `loose`, relative L2 error below `loose`/2."""
     g = np.asarray(g, np.float64).reshape(ref.shape)
     r = np.asarray(ref, np.float64)
     scale = np.abs(r).max() + 1e-30
@@ -64,7 +118,21 @@ def assert_grad_close(g, ref, name, tight=2e-4, loose=2e-2, max_flip_frac=0.15):
     if err.max() <= tight:
         return
     rows = err.reshape(err.shape[0], -1).max(axis=1) if err.ndim > 1 else err
-    nbad = int((rows > tight).sum())
+    bad = np.nonzero(rows > tight)[0]
+    if candidates is not None:
+        prefix = name.rsplit(".", 1)[0]
+        allowed = candidates.get(prefix, set()) if err.ndim >= 1 and name.rsplit(".", 1)[-1] in ("weight", "bias") else set()
+        unexplained = [int(b) for b in bad if int(b) not in allowed]
+        FLIP_LOG.append({"tensor": name, "rows_over_tight": len(bad), "candidate_rows": len(allowed), "unexplained": len(unexplained),
+                         "max_rel_err": float(err.max()), "output_candidates": n_out_candidates})
+        worst_unexplained = max([rows[b] for b in unexplained], default=0.0)
+        # a flip upstream of this tensor ripples into every row, far below north_star's 1e-3; an output-pixel candidate
+        # (clamp bound / L1 sign) does the same to every tensor
+        assert worst_unexplained <= (strict if (candidates or n_out_candidates) else tight), \
+            f"{name}: rows {unexplained[:8]} exceed {tight} (max {worst_unexplained:.3e}) without a flip candidate"
+        assert err.max() <= loose, f"{name}: max rel err {err.max():.3e} > loose {loose}"
+        return
+    nbad = len(bad)
     assert err.max() <= loose, f"{name}: max rel err {err.max():.3e} > loose {loose}"
     assert nbad <= max(1, int(max_flip_frac * rows.size)), f"{name}: {nbad}/{rows.size} rows exceed {tight}"
     l2 = np.linalg.norm(g - r) / (np.linalg.norm(r) + 1e-30)

@@ -72,6 +72,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
     char* in_lds = smem;
     char* w_lds = smem + IN_LDS_BYTES;
 
+#ifdef XSD_DIAG   // diagnostic library variant only (make diag; selected with XSD_LIB): ablation knobs are compiled out otherwise
+    const int abl = P.ablate;
+#else
+    constexpr int abl = 0;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = tid >> 6;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
         const int hy = p / HALO_W, hx = p - hy * HALO_W;
         const int gy = T.y0 - 1 + hy, gx = T.x0 - 1 + hx;
         const bool ok = (slot < (SPLIT ? SP_SLOTS : IN_SLOTS)) && (gy >= 0) && (gy < P.H) && (gx >= 0) && (gx < P.W);
-        return (ok && !(P.ablate & 1)) ? gy * rs + gx * ps + sub : -1;
+        return (ok && !(abl & 1)) ? gy * rs + gx * ps + sub : -1;
     };
     int goff[SPLIT ? NR : 1]; // split mode keeps the 6 offsets in registers; fp32 mode (11 slots) recomputes them
     auto tile_offsets = [&](const TileXY& T, int rs, int ps) {
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
     };
     auto load_w = [&](int s) {
         const f32x4* src = reinterpret_cast<const f32x4*>(P.wstep[s]);
-        if (P.ablate & 2) return;
+        if (abl & 2) return;
 #pragma unroll
         for (int r = 0; r < W_ROUNDS; ++r) pw[r] = src[r * 256 + tid];
     };
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
     };
 
     const char* wl = w_lds + lane * 16;
-    auto compute = [&]() { if (!(P.ablate & 8)) conv_compute<SPLIT, ROW_BYTES>(in_lds, wl, abase, acc); };
+    auto compute = [&]() { if (!(abl & 8)) conv_compute<SPLIT, ROW_BYTES>(in_lds, wl, abase, acc); };
 
     // Epilogue: each lane owns one pixel and 16 channels as four float4 groups -> 16-B loads/stores; lanes l and l+32
     // cover adjacent 16-B chunks, so every store instruction writes 32 x 32 contiguous bytes.
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
         float* dst = o.p + (long long)T.b * o.bs;
         const long long sb = (long long)T.b * P.std_bs;
         const int x = T.x0 + l31;
-        if (x >= P.W || (P.ablate & 4)) return;
+        if (x >= P.W || (abl & 4)) return;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int y = T.y0 + wv * 2 + r;
@@ -241,13 +246,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
     if (items <= 0) return;
     // stagger: the two workgroups that share a CU run the same program; started together they phase-lock (both in the
     // MFMA loop, then both staging).  Delay the second half of the grid by about half a step (diagnostic knob bit 16+).
-    if ((P.ablate >> 4) && (int)blockIdx.x >= (G >> 1)) {
-        for (int q = 0; q < (P.ablate >> 4); ++q) __builtin_amdgcn_s_sleep(127);
+    if ((abl >> 4) && (int)blockIdx.x >= (G >> 1)) {
+        for (int q = 0; q < (abl >> 4); ++q) __builtin_amdgcn_s_sleep(127);
     }
-    // diagnostic stamps (P.dbg != null only in profiling builds of the HOST side; never in timed runs)
+    // diagnostic phase stamps: compiled in only under XSD_DIAG (diagnostic library variant)
     unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t0 = 0;
+#ifdef XSD_DIAG
     const bool stamp = P.dbg != nullptr;
+#else
+    constexpr bool stamp = false;
+#endif
     auto tick = [&](int i) {
         if (stamp) { const unsigned long long t = __builtin_readcyclecounter(); st[i] += t - t0; t0 = t; }
     };

@@ -46,6 +46,11 @@ template <bool MULTI_OUT>
 __global__ __launch_bounds__(QT, 2) void conv3x3_p16_kernel(const ConvParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef XSD_DIAG   // diagnostic library variant only (make diag; selected with XSD_LIB): ablation knobs are compiled out otherwise
+    const int abl = P.ablate;
+#else
+    constexpr int abl = 0;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(QT, 2) void conv3x3_p16_kernel(const ConvParams P)
         const PlaneIn pl = P.in[s];
         const char* base = reinterpret_cast<const char*>(pl.p + (long long)T.b * pl.bs) + s2 * 32;
         char* dst = smem + buf * QIN_BYTES;
-        if (P.ablate & 1) return;
+        if (abl & 1) return;
 #pragma unroll
         for (int k = 0; k < QNG; ++k) {
             const int g = wv + k * QW;
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(QT, 2) void conv3x3_p16_kernel(const ConvParams P)
     auto dma_w = [&](int s, int s2, int buf) {
         const char* src = reinterpret_cast<const char*>(P.wstep[s]) + s2 * QW_BYTES + lane * 16;
         char* dst = smem + (buf ? Q_W1 : Q_W0);
-        if (P.ablate & 2) return;
+        if (abl & 2) return;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int g = wv + k * QW;
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(QT, 2) void conv3x3_p16_kernel(const ConvParams P)
         float* dst = o.p + (long long)T.b * o.bs;
         const long long sb = (long long)T.b * P.std_bs;
         const int x = T.x0 + l31;
-        if (x >= P.W || (P.ablate & 4)) return;
+        if (x >= P.W || (abl & 4)) return;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int y = T.y0 + wv * 2 + r;
@@ -324,12 +329,12 @@ __global__ __launch_bounds__(QT, 2) void conv3x3_p16_kernel(const ConvParams P)
             const bool new_tile = more && s2 && (s + 1 == nsteps);
             if (more) dma_w(s_n, s2 ^ 1, s2 ^ 1);
             if (s2 == 0) init_acc(s);
-            if (!(P.ablate & 8)) compute(s2, s2);
+            if (!(abl & 8)) compute(s2, s2);
             int nst = 0;
             if (s2 == 1) {
                 epilogue(s, cur);
                 const int y = cur.y0 + wv * 2;
-                nst = (P.ablate & 4) ? 0 : 4 * ((y < P.H) + (y + 1 < P.H));
+                nst = (abl & 4) ? 0 : 4 * ((y < P.H) + (y + 1 < P.H));
             }
             if (more) {
                 wait_and_barrier(nst);
@@ -367,13 +372,13 @@ __global__ __launch_bounds__(QT, 2) void conv3x3_p16_kernel(const ConvParams P)
             const int s_n = s2 ? ((s + 1 == nsteps) ? 0 : s + 1) : s;
             int young = 0;
             if (more) dma_w(s_n, s2 ^ 1, s2 ^ 1);              // read by half-step u+1: issued FIRST
-            if (u + 2 < nhalf) { dma_next_in(db); young = (P.ablate & 1) ? 0 : n_in_chunks; db = db == 2 ? 0 : db + 1; } // read by u+2
+            if (u + 2 < nhalf) { dma_next_in(db); young = (abl & 1) ? 0 : n_in_chunks; db = db == 2 ? 0 : db + 1; } // read by u+2
             if (s2 == 0 && s == 0) init_acc(0);
-            if (!(P.ablate & 8)) { if (P.ablate & 16384) compute(ib, s2); else compute_rows(ib, s2); }
+            if (!(abl & 8)) { if (abl & 16384) compute(ib, s2); else compute_rows(ib, s2); }
             if (s2 == 1 && s == nsteps - 1) {
                 epilogue(0, cur);
                 const int y = cur.y0 + wv * 2;
-                young += (P.ablate & 4) ? 0 : (4 + (P.out[0].bits_out != nullptr)) * ((y < P.H) + (y + 1 < P.H));
+                young += (abl & 4) ? 0 : (4 + (P.out[0].bits_out != nullptr)) * ((y < P.H) + (y + 1 < P.H));
             }
             if (more) wait_and_barrier(young);
             ib = ib == 2 ? 0 : ib + 1;

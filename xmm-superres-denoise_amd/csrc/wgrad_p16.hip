@@ -43,6 +43,11 @@ __device__ __forceinline__ bf16x8 tr_frag16(const char* lds_lane_base, int byte_
 __global__ __launch_bounds__(RT, 2) void wgrad_p16_kernel(const WgradParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef XSD_DIAG   // diagnostic library variant only (make diag; selected with XSD_LIB): ablation knobs are compiled out otherwise
+    const int abl = P.ablate;
+#else
+    constexpr int abl = 0;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // tile row
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(RT, 2) void wgrad_p16_kernel(const WgradParams P)
                 __builtin_amdgcn_global_load_lds((gptr_t)(ok ? src + 64 : zero), (lptr_t)(dst + R_XL + g * 1024), 16, 0, 0);
             }
         }
-        if ((P.ablate & 4096) && t != part) return; // diagnostic: stale (but realistic) G tiles after the first
+        if ((abl & 4096) && t != part) return; // diagnostic: stale (but realistic) G tiles after the first
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int g = wv + 8 * k;

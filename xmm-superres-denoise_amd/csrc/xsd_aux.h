@@ -22,7 +22,6 @@ struct MaskPadParams {
 };
 
 hipError_t launch_conv3x3_mfma(const ConvParams& p, int split, hipStream_t stream);
-hipError_t launch_conv3x3_big(const ConvParams& p, int split, hipStream_t stream);
 hipError_t launch_wgrad_mfma(const WgradParams& p, int split, hipStream_t stream);
 hipError_t launch_wgrad_reduce(const WgradReduceParams& r, hipStream_t stream);
 hipError_t launch_edge_expand(const EdgeExpandParams& p, hipStream_t s);
@@ -45,7 +44,6 @@ hipError_t launch_conv3x3_s3(const ConvParams& p, hipStream_t stream);
 hipError_t launch_wgrad_s3(const WgradParams& p, hipStream_t stream);
 hipError_t launch_plane_convert(const float* in, float* out, long long npix, int to_p16, hipStream_t s);
 hipError_t launch_conv3x3_p16(const ConvParams& p, hipStream_t stream);
-hipError_t launch_conv3x3_p16v2(const ConvParams& p, int rowreuse, hipStream_t stream);
 hipError_t launch_wgrad_p16(const WgradParams& p, hipStream_t stream);
 hipError_t launch_pack_edge(const float* w_first, const float* w_last, float* ff, float* fb, float* lf, float* lb,
                             hipStream_t s);

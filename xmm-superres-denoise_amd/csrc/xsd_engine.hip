@@ -78,11 +78,9 @@ struct xsd_engine {
     float* pk_bwd = nullptr;
     unsigned short* pk_fwd_s = nullptr; // bf16x3 (hi|lo) panels, same byte size / offsets as pk_fwd / pk_bwd
     unsigned short* pk_bwd_s = nullptr;
-    int p16v2 = 0;             // math mode 2 K-loop convs: 0 = conv3x3_p16 (all waves DMA + MFMA), 1 = role-split conv3x3_p16v2, 2 = role-split + row reuse
-    int chunk = 0;             // images per dense-block sweep (0 = whole batch): keeps one block's planes in the 256 MB Infinity Cache
-    int ablate = 0;            // diagnostic (env XSD_ABLATE)
-    int big = 0;               // conv structure: 0 = 8x32 tile, 2 WG/CU; 1 = 16x32 tile, 1 WG/CU, LDS-DMA weight ring
-    int math = 0;              // 0 = exact fp32 MFMA, 1 = bf16x3 split MFMA (conv forward + input-gradient)
+    int chunk = 0;             // diagnostic library only (env XSD_CHUNK): images per dense-block sweep (0 = whole batch)
+    int ablate = 0;            // diagnostic library only (env XSD_ABLATE): ablation knobs of the kernels
+    int math = 3;              // include/xsd.h: xsd_set_math (default: bf16x6, the fp32-class split mode)
     float* pk_edge = nullptr; // first_fwd, first_bwd, last_fwd, last_bwd (288 each)
     float* pk_sbias = nullptr;
     PackDesc* descs_dev = nullptr;
@@ -256,7 +254,7 @@ struct Builder {
             p.dbg = eng->dbg;
             p.ablate = eng->ablate;
             p.zero = eng->zero_page;
-            return prof_launch(eng, 0, flop, bytes, s, [&]() { return eng->math == 3 ? launch_conv3x3_s3(p, s) : eng->math == 2 ? ((eng->p16v2 && p.n_out == 1) ? launch_conv3x3_p16v2(p, eng->p16v2 == 2, s) : launch_conv3x3_p16(p, s)) : eng->big ? launch_conv3x3_big(p, eng->math, s) : launch_conv3x3_mfma(p, eng->math, s); });
+            return prof_launch(eng, 0, flop, bytes, s, [&]() { return eng->math == 3 ? launch_conv3x3_s3(p, s) : eng->math == 2 ? launch_conv3x3_p16(p, s) : launch_conv3x3_mfma(p, eng->math, s); });
         };
     }
     // wgrad + fixed-order reduce into the flat gradient vector
@@ -302,7 +300,7 @@ struct Builder {
         e->bwd_stages.assign(blocks + 2, {});
 
         struct RdbAct { float* xin; float* xs[4]; float* out; unsigned short* xb[4]; };
-        const bool use_bits = train && e->math == 2 && e->p16v2 == 0; // compact lrelu' masks (conv3x3_p16 epilogue)
+        const bool use_bits = train && e->math == 2; // compact lrelu' masks (conv3x3_p16 epilogue)
         std::vector<RdbAct> acts(blocks * 3);
         std::vector<float*> rin(blocks + 1);
 
@@ -554,7 +552,11 @@ static int ensure_plan(xsd_engine* e, int B, int H, int W, bool train)
 extern "C" {
 
 const char* xsd_last_error(void) { return g_err.c_str(); }
-const char* xsd_version(void) { return "xsd-hip gfx950 r1"; }
+#ifdef XSD_DIAG
+const char* xsd_version(void) { return "xsd-hip gfx950 r2 (diagnostic variant)"; }
+#else
+const char* xsd_version(void) { return "xsd-hip gfx950 r2"; }
+#endif
 
 int xsd_create(const xsd_config* cfg, xsd_engine** out)
 {
@@ -568,10 +570,10 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(XSD_ERR_HIP, "no HIP device available");
     xsd_engine* e = new xsd_engine();
     e->cfg = *cfg;
+#ifdef XSD_DIAG   // the diagnostic library variant (make diag, selected with XSD_LIB) is the only build that reads these
     if (const char* m = getenv("XSD_ABLATE")) e->ablate = atoi(m);
     if (const char* m = getenv("XSD_CHUNK")) e->chunk = atoi(m);
-    if (const char* m = getenv("XSD_P16")) e->p16v2 = strcmp(m, "v3") == 0 ? 2 : strcmp(m, "v2") == 0 ? 1 : 0;
-    if (const char* m = getenv("XSD_CONV")) e->big = strcmp(m, "big") == 0 ? 1 : 0;
+#endif
     if (const char* m = getenv("XSD_MATH")) e->math = (strcmp(m, "bf16x6") == 0 || strcmp(m, "3") == 0) ? 3 : (strcmp(m, "bf16x3_p16") == 0 || strcmp(m, "2") == 0) ? 2 : (strcmp(m, "bf16x3") == 0 || strcmp(m, "1") == 0) ? 1 : 0;
     const int blocks = cfg->num_res_blocks, nup = cfg->kind == XSD_KIND_SR ? cfg->num_upsample : 0;
     long long off = 0, pk = 0, sb = 0;
@@ -906,8 +908,8 @@ static hipError_t run_conv(xsd_engine* e, ConvParams& p, hipStream_t s)
     p.zero = e->zero_page;
     for (int i = 0; i < (p.n_out > 1 ? p.n_out : p.n_in); ++i) p.wstep[i] = p.wpanel + (long long)i * PANEL_FLOATS;
     if (e->math == 3) return launch_conv3x3_s3(p, s);
-    if (e->math == 2) return (e->p16v2 && p.n_out == 1) ? launch_conv3x3_p16v2(p, e->p16v2 == 2, s) : launch_conv3x3_p16(p, s);
-    return e->big ? launch_conv3x3_big(p, e->math, s) : launch_conv3x3_mfma(p, e->math, s);
+    if (e->math == 2) return launch_conv3x3_p16(p, s);
+    return launch_conv3x3_mfma(p, e->math, s);
 }
 
 int xsd_test_conv3x3(xsd_engine* e, const float* const* in_planes, int n_in, const float* dev_w_oihw, const float* dev_bias,

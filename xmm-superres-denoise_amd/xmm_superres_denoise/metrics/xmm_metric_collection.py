@@ -53,6 +53,11 @@ class XMMMetricCollection:
             out, _ = self._eval._eval(p, t, False)
             self.states[mode].add(out, p.numel(), nimg)
 
+    def sync(self, group=None) -> None:
+        """all-reduce the per-mode epoch states over the ranks (sum / min / max), see EpochState.sync"""
+        for st in self.states.values():
+            st.sync(group)
+
     def compute(self) -> dict:
         res = {}
         for mode, st in self.states.items():

@@ -105,17 +105,21 @@ class Model(nn.Module):
         return None
 
     def _on_epoch_end(self, stage):
-        """reference models/model.py:109-150 without the Lightning logger: returns what it would log.  Multi-GPU runs
-        reduce the returned values like `sync_dist=True` does (mean over ranks) in the training driver."""
+        """reference models/model.py:109-150 without the Lightning logger: returns what it would log.  With several ranks
+        the metric STATES are reduced first (sum / min / max, what torchmetrics' dist_reduce_fx does at compute()), so every
+        rank returns the global epoch value."""
         if stage == "train":
             if self.loss is not None:
                 self.loss.reset()
             return {}
+        self.loss.sync()
         logged = {f"{stage}/loss": self.loss.compute()}
         self.loss.reset()
         for name in ("metrics", "ext_metrics", "in_metrics", "in_ext_metrics"):
             coll = getattr(self, name)
             if coll is not None:
+                if hasattr(coll, "sync"):
+                    coll.sync()
                 logged.update(coll.compute())
                 coll.reset()
                 if name.startswith("in_"):

@@ -119,6 +119,13 @@ class _GeneratorRRDB(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, num_filters: int, num_res_blocks: int,
                  memory_efficient: bool = False):
         super().__init__()
+        # The reference accepts any widths (generator_rrdb.py:10-54); this engine's kernels are specialised for the shipped
+        # configuration (res/configs/models.toml: 32 filters, one image channel).  Say so HERE, not at the first forward.
+        if in_channels != 1 or out_channels != 1 or num_filters != 32:
+            raise ValueError(f"the MI355X engine supports in_channels = out_channels = 1 and num_filters = 32 "
+                             f"(got {in_channels}, {out_channels}, {num_filters})")
+        if not 1 <= int(num_res_blocks) <= 64:
+            raise ValueError(f"num_res_blocks must be in [1, 64] (got {num_res_blocks})")
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.num_filters = num_filters
@@ -140,7 +147,7 @@ class _GeneratorRRDB(nn.Module):
         self._engine_dev = None
         self._flat = None
         self._plist = None
-        self._math = None  # None: engine default (env XSD_MATH, else fp32)
+        self._math = None  # None: engine default (env XSD_MATH, else bf16x6)
 
     # ---- flat parameter buffer ---------------------------------------------------------------------------------
     def _num_upsample(self):
@@ -215,6 +222,8 @@ class GeneratorRRDB_SR(_GeneratorRRDB):
                  num_upsample: int = 2, memory_efficient: bool = False):
         super().__init__(in_channels=in_channels, out_channels=out_channels, num_filters=num_filters,
                          num_res_blocks=num_res_blocks, memory_efficient=memory_efficient)
+        if num_upsample not in (1, 2):
+            raise ValueError(f"the MI355X engine supports num_upsample 1 or 2 (got {num_upsample})")
         self.num_upsample = num_upsample
         layers = []
         for _ in range(num_upsample):  # reference generator_rrdb.py:91-99

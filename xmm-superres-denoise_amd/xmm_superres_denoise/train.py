@@ -83,18 +83,13 @@ def fit(name: str = "rrdb_denoise", lr_res: int = 416, batch_size: int = 4, step
         losses.append(float(loss))
         if rank == 0 and log_every and it % log_every == 0:
             print(f"step {it}: train/loss {losses[-1]:.6f}", flush=True)
-    if val_batches > 0:       # one validation epoch (reference model.py:53-60); values are averaged over ranks like sync_dist
-        model.on_validation_start()
+    if val_batches > 0:       # one validation epoch (reference model.py:53-60); metric states are reduced over the ranks
+        model.on_validation_start()                                    # inside on_validation_epoch_end (sum / min / max)
         for _ in range(val_batches):
             lr_img = torch.rand((per_rank, 1, lr_res, lr_res), generator=g).to(dev)
             hr_img = torch.rand((per_rank, 1, hr_res, hr_res), generator=g).to(dev)
             model.validation_step((lr_img, hr_img))
         logged = model.on_validation_epoch_end()
-        if world > 1:
-            for k in logged:
-                t = logged[k].detach().float().clone()
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                logged[k] = t / world
         if rank == 0 and log_every:
             print("validation: " + ", ".join(f"{k} {float(v):.6f}" for k, v in sorted(logged.items())), flush=True)
     if checkpoint and rank == 0:

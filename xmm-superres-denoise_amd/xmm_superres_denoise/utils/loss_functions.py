@@ -78,6 +78,21 @@ class EpochState:
             self.acc = torch.stack([a[0] + cur[0], a[1] + cur[1], torch.minimum(a[2], cur[2]), torch.maximum(a[3], cur[3]),
                                     a[4] + cur[4], a[5] + cur[5], a[6] + cur[6], a[7] + cur[7], a[8] + cur[8]])
 
+    def sync(self, group=None) -> None:
+        """Reduce the STATES over the ranks before compute(), as torchmetrics does (dist_reduce_fx: "sum" for the sums and
+        counts, "min" / "max" for the target range; reference metrics/metrics.py:16-21): PSNR of the pooled squared error,
+        not a mean of per-rank PSNRs."""
+        import torch.distributed as dist
+        if self.acc is None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        a = self.acc.clone()
+        sums = a[[0, 1, 4, 5, 6, 7, 8]].contiguous()
+        lo, hi = a[2:3].contiguous(), a[3:4].contiguous()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        self.acc = torch.stack([sums[0], sums[1], lo[0], hi[0], sums[2], sums[3], sums[4], sums[5], sums[6]])
+
     def compute(self) -> dict:
         a = self.acc
         mse = a[0] / a[1]
@@ -158,6 +173,9 @@ class Loss:
         out, _ = self._eval(preds.contiguous(), target.contiguous(), False)
         self.last_values = out
         self._epoch.add(out, preds.numel(), preds.shape[0])
+
+    def sync(self, group=None) -> None:
+        self._epoch.sync(group)
 
     def compute(self) -> torch.Tensor:
         vals = self._epoch.compute()
