@@ -4,10 +4,12 @@
 // (rrdb_blocks.py:27-31; generator_rrdb.py:38-44,95,101):
 //     dW[co][ci][tap] = sum_{b,y,x} G[b,y,x,co] * X[b,y+dy-1,x+dx-1,ci],   db[co] = sum G[..,co]
 // GEMM view: M = 32 input channels (one plane), N = 32 output channels, K = pixels; nine 32x32 accumulators (one per
-// tap) per wave, kept in registers across all tiles of the workgroup; wave w owns row w of each 8x32 tile.  Both MFMA
-// operands need K (8 consecutive pixels) contiguous per lane while memory is [pixel][channel], so LDS holds six images
-// [pixel][32 x bf16] (X_hi, X_mid, X_lo, G_hi, G_mid, G_lo; 114,432 B, one workgroup per CU) read with the transposing
-// ds_read_b64_tr_b16.  Fixed-order two-stage reduction (wgrad_reduce_kernel): bitwise reproducible, no atomics.
+// tap) per wave, kept in registers across all tiles of the workgroup.  Workgroup = 256 threads on a 4 x 32-pixel tile
+// (wave w owns row w), TWO workgroups per CU: the staging of a tile (fp32 -> registers a tile ahead; VALU split and LDS
+// writes between two barriers) is serial inside a workgroup, and the co-resident workgroup's MFMAs run beside it.  Both
+// MFMA operands need K (8 consecutive pixels) contiguous per lane while memory is [pixel][channel], so LDS holds six
+// images [pixel][32 x bf16] (X_hi, X_mid, X_lo over the 6 x 34 halo, G_hi, G_mid, G_lo; 63,744 B) read with the
+// transposing ds_read_b64_tr_b16.  Fixed-order two-stage reduction (wgrad_reduce_kernel): bitwise reproducible, no atomics.
 #include "xsd_kernels.h"
 
 namespace xsd {
@@ -20,15 +22,17 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) f32x4* gf32x4p;
 
-constexpr int W3_THREADS = 512;
-constexpr int W3_X_SLOTS = HALO_PX * 8;                               // 2720 (pixel, channel quad) slots
-constexpr int W3_X_ROUNDS = (W3_X_SLOTS + W3_THREADS - 1) / W3_THREADS; // 6
-constexpr int W3_G_SLOTS = TILE_H * TILE_W * 8;                       // 2048
+constexpr int W3_TH = 4;                                              // tile rows = waves per workgroup
+constexpr int W3_THREADS = 64 * W3_TH;                                // 256
+constexpr int W3_HPX = (W3_TH + 2) * HALO_W;                          // 204 halo pixels
+constexpr int W3_X_SLOTS = W3_HPX * 8;                                // 1632 (pixel, channel quad) slots
+constexpr int W3_X_ROUNDS = (W3_X_SLOTS + W3_THREADS - 1) / W3_THREADS; // 7
+constexpr int W3_G_SLOTS = W3_TH * TILE_W * 8;                        // 1024
 constexpr int W3_G_ROUNDS = W3_G_SLOTS / W3_THREADS;                  // 4
-constexpr int W3_XT = HALO_PX * 64;                                   // 21,760 B per X term image
-constexpr int W3_GT = TILE_H * TILE_W * 64;                           // 16,384 B per G term image
-constexpr int W3_G_OFF = 3 * W3_XT;                                   // 65,280
-constexpr int W3_LDS_BYTES = W3_G_OFF + 3 * W3_GT;                    // 114,432
+constexpr int W3_XT = W3_HPX * 64;                                    // 13,056 B per X term image
+constexpr int W3_GT = W3_TH * TILE_W * 64;                            // 8,192 B per G term image
+constexpr int W3_G_OFF = 3 * W3_XT;                                   // 39,168
+constexpr int W3_LDS_BYTES = (W3_G_OFF + 3 * W3_GT) > W3_TH * 4096 ? (W3_G_OFF + 3 * W3_GT) : W3_TH * 4096;   // 63,744
 
 // exact 3-term split of 4 fp32 values into packed bf16 pairs
 __device__ __forceinline__ void w3_split4(const f32x4& a, u32x2& hi, u32x2& mid, u32x2& lo)
@@ -65,16 +69,24 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradPara
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wv = tid >> 6; // 0..7 = tile row
+    const int wv = tid >> 6; // tile row
     const int h = lane >> 5;
     const int l31 = lane & 31;
 
-    const int part = blockIdx.x;
-    const int j = blockIdx.y;  // input plane
-    const int n = blockIdx.z;  // G chunk
+    // 1-D grid, decoded so that the n_in workgroups that read the SAME G tiles (same `part`, input planes j = 0..n_in-1)
+    // have linear ids 8 apart: the dispatcher deals consecutive ids round-robin over the 8 XCDs, so they land on one XCD
+    // back to back and the G tile is fetched from HBM once per group and served from that XCD's L2 to the others.
+    const int lin = blockIdx.x;
+    const int xcd = lin & 7, qq = lin >> 3;
+    const int j = qq % P.n_in;                        // input plane
+    const int rest = qq / P.n_in;
+    const int parts8 = P.nparts >> 3;
+    const int part = (rest % parts8) * 8 + xcd;
+    const int n = rest / parts8;                      // G chunk
     const PlaneIn xp = P.x[j];
     const PlaneIn gp = P.g[n];
-    const int ntiles = P.B * P.tilesY * P.tilesX;
+    const int tilesY = (P.H + W3_TH - 1) / W3_TH;
+    const int ntiles = P.B * tilesY * P.tilesX;
 
     f32x16 acc[9];
 #pragma unroll
@@ -90,9 +102,9 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradPara
     auto load_tile = [&](int t) {
         const int tx = t % P.tilesX;
         const int t2 = t / P.tilesX;
-        const int ty = t2 % P.tilesY;
-        const int b = t2 / P.tilesY;
-        const int x0 = tx * TILE_W, y0 = ty * TILE_H;
+        const int ty = t2 % tilesY;
+        const int b = t2 / tilesY;
+        const int x0 = tx * TILE_W, y0 = ty * W3_TH;
         const float* xb = xp.p + (long long)b * xp.bs;
         const float* gb = gp.p + (long long)b * gp.bs;
 #pragma unroll
@@ -168,26 +180,24 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradPara
         W3_TICK(0);
         // Running accumulators take every product: 12 roundings per tile row and tap, against 32 for an fp32 fma chain over
         // the same 32 pixels (single-layer error vs float64: tools/dbg_layer.py).
-        bf16x8 g[2][3];
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
+        for (int mf = 0; mf < 2; ++mf) {
+            bf16x8 g[3];
 #pragma unroll
-            for (int term = 0; term < 3; ++term) g[mf][term] = w3_tr_frag(gbase, term * W3_GT + 16 * mf * 64);
+            for (int term = 0; term < 3; ++term) g[term] = w3_tr_frag(gbase, term * W3_GT + 16 * mf * 64);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
-#pragma unroll
-            for (int mf = 0; mf < 2; ++mf) {
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap % 3;
                 const int off = (dy * HALO_W + dx + 16 * mf) * 64;
                 const bf16x8 xh = w3_tr_frag(xbase, off);
                 const bf16x8 xm = w3_tr_frag(xbase, W3_XT + off);
                 const bf16x8 xl = w3_tr_frag(xbase, 2 * W3_XT + off);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, g[mf][0], acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, g[mf][2], acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, g[mf][1], acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, g[mf][0], acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, g[mf][1], acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, g[mf][0], acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, g[0], acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, g[2], acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, g[1], acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, g[0], acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, g[1], acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, g[0], acc[tap], 0, 0, 0);
             }
         }
         W3_TICK(1);
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradPara
     }
 #endif
 
-    // ---- cross-wave reduction through LDS, one tap at a time (8 waves x 4 KiB), then one coalesced store per tap
+    // ---- cross-wave reduction through LDS, one tap at a time (one 4 KiB slab per wave), then one coalesced store per tap
     float* red = reinterpret_cast<float*>(smem);
     float* outp = P.partial + ((((long long)part * P.n_g + n) * P.n_in + j) * 9) * 1024;
 #pragma unroll
@@ -251,7 +261,8 @@ hipError_t launch_wgrad_s3(const WgradParams& p, hipStream_t stream)
         done = true;
     }
     if (!p.zero) return hipErrorInvalidValue;
-    const dim3 g(p.nparts, p.n_in, p.n_g), b(W3_THREADS);
+    if (p.nparts & 7) return hipErrorInvalidValue;
+    const dim3 g(p.nparts * p.n_in * p.n_g), b(W3_THREADS);
     hipLaunchKernelGGL(wgrad_s3_kernel, g, b, W3_LDS_BYTES, stream, p);
     return hipGetLastError();
 }

@@ -266,12 +266,12 @@ struct Builder {
         memset(&wp, 0, sizeof(wp));
         wp.B = B; wp.H = H << level; wp.W = W << level;
         wp.tilesX = (wp.W + TILE_W - 1) / TILE_W; wp.tilesY = (wp.H + TILE_H - 1) / TILE_H;
-        wp.n_in = (int)xs.size(); wp.n_g = (int)gs.size(); wp.nparts = e->nparts;
+        wp.n_in = (int)xs.size(); wp.n_g = (int)gs.size(); wp.nparts = e->math == 3 ? 2 * e->nparts : e->nparts;   // mode 3: two workgroups per CU
         for (size_t i = 0; i < xs.size(); ++i) wp.x[i] = xs[i];
         for (size_t i = 0; i < gs.size(); ++i) wp.g[i] = gs[i];
         WgradReduceParams rp;
         memset(&rp, 0, sizeof(rp));
-        rp.nparts = e->nparts; rp.n_in = wp.n_in; rp.n_g = wp.n_g; rp.cin_total = cw.cin; rp.cout_total = cw.cout;
+        rp.nparts = wp.nparts; rp.n_in = wp.n_in; rp.n_g = wp.n_g; rp.cin_total = cw.cin; rp.cout_total = cw.cout;
         rp.shuffle = cw.shuffle; rp.scale = scale;
         const long long w_off = cw.w_off, b_off = cw.b_off;
         const double px = (double)wp.B * wp.H * wp.W;
@@ -621,8 +621,8 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     CK(hipMalloc((void**)&e->pk_sbias, sizeof(float) * (sb ? sb : 1)));
     CK(hipMalloc((void**)&e->descs_dev, sizeof(PackDesc) * descs.size()));
     CK(hipMemcpy(e->descs_dev, descs.data(), sizeof(PackDesc) * descs.size(), hipMemcpyHostToDevice));
-    CK(hipMalloc((void**)&e->wg_partial, sizeof(float) * (size_t)e->nparts * 5 * PANEL_FLOATS));
-    CK(hipMalloc((void**)&e->wg_bias_partial, sizeof(float) * (size_t)e->nparts * 4 * 32));
+    CK(hipMalloc((void**)&e->wg_partial, sizeof(float) * (size_t)2 * e->nparts * 5 * PANEL_FLOATS));   // up to 2 x nparts partials (mode 3)
+    CK(hipMalloc((void**)&e->wg_bias_partial, sizeof(float) * (size_t)2 * e->nparts * 4 * 32));
     CK(hipMalloc((void**)&e->edge_partial, sizeof(float) * EDGE_WGRAD_BLOCKS * 321));
     CK(hipMalloc((void**)&e->loss_partial, sizeof(double) * 1024));
 #undef CK
@@ -978,14 +978,14 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
     hipError_t err = run_conv(e, p, s);
     if (err == hipSuccess) {
         WgradParams wp; memset(&wp, 0, sizeof(wp));
-        wp.B = B; wp.H = H; wp.W = W; wp.tilesX = p.tilesX; wp.tilesY = p.tilesY; wp.n_in = n_in; wp.n_g = 1; wp.nparts = e->nparts;
+        wp.B = B; wp.H = H; wp.W = W; wp.tilesX = p.tilesX; wp.tilesY = p.tilesY; wp.n_in = n_in; wp.n_g = 1; wp.nparts = e->math == 3 ? 2 * e->nparts : e->nparts;
         for (int i = 0; i < n_in; ++i) wp.x[i] = b.std_in(ins[i], 0);
         wp.g[0] = b.std_in(g, 0);
         wp.partial = e->wg_partial; wp.bias_partial = e->wg_bias_partial; wp.zero = e->zero_page;
         err = e->math == 3 ? launch_wgrad_s3(wp, s) : e->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, e->math, s);
         if (err == hipSuccess) {
             WgradReduceParams rp; memset(&rp, 0, sizeof(rp));
-            rp.partial = e->wg_partial; rp.bias_partial = e->wg_bias_partial; rp.nparts = e->nparts; rp.n_in = n_in; rp.n_g = 1;
+            rp.partial = e->wg_partial; rp.bias_partial = e->wg_bias_partial; rp.nparts = wp.nparts; rp.n_in = n_in; rp.n_g = 1;
             rp.cin_total = 32 * n_in; rp.cout_total = 32; rp.shuffle = 0; rp.scale = 1.f; rp.dw = dev_dw_oihw; rp.db = dev_db;
             rp.p16 = e->math == 2;
             err = launch_wgrad_reduce(rp, s);
