@@ -266,7 +266,7 @@ def main():
 
     # ---- extra leg (same process, same inputs): another math mode, short run, labelled; never the headline
     extra = None
-    xm = None if (args.no_extra or args.extra_math in ("none", args.math)) else args.extra_math
+    xm = None if (args.no_extra or world > 1 or args.extra_math in ("none", args.math)) else args.extra_math   # N=1 only
     if xm is not None:
         with torch.no_grad():
             y_head = model(x[:2]).clone()

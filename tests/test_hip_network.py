@@ -143,8 +143,10 @@ def test_train_step_adam_matches_oracle():
     md, vd = torch.zeros_like(flat), torch.zeros_like(flat)
     xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
     grads = torch.empty_like(flat)
+    g_min = None
     for step in range(1, 4):
         _, lo, _, go = oracle.l1_train(kind, 32, blocks, p, x, t)
+        g_min = np.abs(go) if g_min is None else np.minimum(g_min, np.abs(go))
         oracle.adam(p, go, mo, vo, step)
         eng.pack(flat)
         y = eng.forward(xd, save_for_backward=True)
@@ -152,11 +154,18 @@ def test_train_step_adam_matches_oracle():
         eng.backward(dy, grads)
         eng.adam_step(flat, grads, md, vd, step)
         assert abs(loss.item() - lo) < 1e-5
-    # Adam's first steps move each weight by ~lr regardless of gradient scale: compare the update direction
-    assert np.abs(flat.cpu().numpy() - p).max() < 2.5e-4
-    d_eng = flat.cpu().numpy() - oracle.flatten_state(state)
-    d_ora = p - oracle.flatten_state(state)
-    assert np.mean(np.sign(d_eng) == np.sign(d_ora)) > 0.98
+    start = oracle.flatten_state(state)
+    d_eng = flat.cpu().numpy().astype(np.float64) - start
+    d_ora = p.astype(np.float64) - start
+    # Adam normalises the step (about lr per step whatever the gradient scale), so a parameter whose gradient is within
+    # rounding of zero may legitimately move either way.  Everywhere else -- gradients that stay above 1e-6 of the largest
+    # in all three steps, 9 parameters in 10 -- the accumulated updates must agree to 5e-8 = 0.05 % of one step
+    # (lr = 1e-4; measured 7.5e-9, one ulp of a weight).
+    solid = g_min > 1e-6 * np.abs(go).max()
+    assert solid.mean() > 0.8
+    assert np.abs(d_eng[solid] - d_ora[solid]).max() < 5e-8, np.abs(d_eng[solid] - d_ora[solid]).max()
+    assert np.abs(d_eng - d_ora).max() < 2.5e-4          # nobody moves by more than the three steps allow
+    assert np.abs(d_ora[solid]).min() > 1e-5             # and the solid ones really moved
 
 
 @pytest.mark.parametrize("math", MATHS)

@@ -1,13 +1,14 @@
-import csv, glob, sys, collections
+import csv, glob, os, sys, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(int)
 for i in (1, 2):
-    f = glob.glob(f'/root/repo/gpurun_out/pmc_{tag}_{i}/*/*counter_collection.csv')[0]
+    f = glob.glob(os.path.join(ROOT, 'gpurun_out', f'pmc_{tag}_{i}', '*', '*counter_collection.csv'))[0]
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if 'conv3x3' not in k and 'wgrad_mfma' not in k: continue
-        name = ('convF' if 'ILb0' in k or '<false' in k else 'convT') if 'conv3x3' in k else 'wgrad'
+        if 'conv3x3' not in k and not ('wgrad_' in k and 'reduce' not in k): continue
+        name = 'conv' if 'conv3x3' in k else 'wgrad'
         agg[name][r['Counter_Name']] += float(r['Counter_Value'])
         if r['Counter_Name'] in ('SQ_WAVE_CYCLES', 'SQ_WAIT_INST_LDS'): cnt[(name, i)] += 1
 for name, d in agg.items():
