@@ -104,3 +104,39 @@ def test_constructor_rejects_unsupported_widths_early():
         M.GeneratorRRDB_SR(3, 1, 32, 1)
     with pytest.raises(ValueError, match="num_upsample"):
         M.GeneratorRRDB_SR(1, 1, 32, 1, num_upsample=3)
+
+
+def test_bench_contract_without_gpu():
+    """bench.py's static contract, checked without touching a GPU: the math table agrees with the engine's, the default
+    math is an fp32-class mode, and --gpus N > 1 outside torchrun takes the self-launch path (parent starts
+    torch.distributed.run with N ranks and never calls torch.cuda)."""
+    import importlib.util
+    import sys
+    from unittest import mock
+    from xmm_superres_denoise.engine import Engine
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert set(bench.MATHS) == set(Engine.MATH)
+    assert bench.MATHS[bench.DEFAULT_MATH][2] is True                      # headline math is fp32-class
+    assert not bench.MATHS["bf16x3_p16"][2] and not bench.MATHS["bf16x3"][2]
+    calls = {}
+
+    def fake_run(cmd, env=None):
+        calls["cmd"], calls["env"] = cmd, env
+        return mock.Mock(returncode=0)
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    with mock.patch.dict(os.environ, env, clear=True), mock.patch("subprocess.run", fake_run), \
+            mock.patch.object(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"]), \
+            mock.patch("torch.cuda.device_count", side_effect=AssertionError("parent must not touch the GPU")):
+        with pytest.raises(SystemExit) as e:
+            bench.main()
+    assert e.value.code == 0
+    cmd = calls["cmd"]
+    assert "torch.distributed.run" in cmd and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and calls["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    with mock.patch.dict(os.environ, {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}), \
+            mock.patch.object(sys, "argv", ["bench.py", "--gpus", "4"]):
+        with pytest.raises(SystemExit, match="does not match"):
+            bench.main()
