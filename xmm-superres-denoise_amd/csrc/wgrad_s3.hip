@@ -67,6 +67,11 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradPara
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+#ifdef XSD_DIAG   // ablation bits of the diagnostic library (timing experiments only; results are garbage when set)
+    const int abl = P.ablate;
+#else
+    constexpr int abl = 0;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = tid >> 6; // tile row
@@ -99,6 +104,15 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradPara
     f32x4 pg[W3_G_ROUNDS];
     const float* zero = reinterpret_cast<const float*>(P.zero);
 
+    // staging slots of this thread, decoded once: X round r -> halo pixel (hy, hx) and channel quad c, packed hy | hx<<8 | c<<16
+    int xslot[W3_X_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < W3_X_ROUNDS; ++r) {
+        const int slot = r * W3_THREADS + tid;
+        const int p = slot >> 3, c = slot & 7;
+        const int hy = p / HALO_W, hx = p - hy * HALO_W;
+        xslot[r] = slot < W3_X_SLOTS ? (hy | (hx << 8) | (c << 16)) : -1;
+    }
     auto load_tile = [&](int t) {
         const int tx = t % P.tilesX;
         const int t2 = t / P.tilesX;
@@ -109,14 +123,13 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradPara
         const float* gb = gp.p + (long long)b * gp.bs;
 #pragma unroll
         for (int r = 0; r < W3_X_ROUNDS; ++r) {
-            const int slot = r * W3_THREADS + tid;
-            const int p = slot >> 3, c = slot & 7;
-            const int hy = p / HALO_W, hx = p - hy * HALO_W;
-            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-            const bool ok = (slot < W3_X_SLOTS) && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+            const int w = xslot[r];
+            const int gy = y0 - 1 + (w & 0xff), gx = x0 - 1 + ((w >> 8) & 0xff);
+            const bool ok = w >= 0 && (unsigned)gy < (unsigned)P.H && (unsigned)gx < (unsigned)P.W;
             // unconditional load (padding reads the zero page): a branch around it would make hipcc wait for the whole
-            // prefetch at the join, i.e. BEFORE the MFMAs it is meant to overlap
-            px[r] = *(gf32x4p)(ok ? xb + (long long)gy * xp.rs + gx * xp.ps + c * 4 : zero);
+            // prefetch at the join, i.e. BEFORE the MFMAs it is meant to overlap.  In-image offsets fit 32 bits
+            // (xsd_forward rejects larger images).
+            px[r] = *(gf32x4p)(ok ? xb + (gy * xp.rs + gx * xp.ps + ((w >> 16) & 7) * 4) : zero);
         }
 #pragma unroll
         for (int r = 0; r < W3_G_ROUNDS; ++r) {
@@ -124,7 +137,7 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradPara
             const int p = slot >> 3, c = slot & 7;
             const int gy = y0 + (p >> 5), gx = x0 + (p & 31);
             const bool ok = gy < P.H && gx < P.W;
-            pg[r] = *(gf32x4p)(ok ? gb + (long long)gy * gp.rs + gx * gp.ps + c * 4 : zero);
+            pg[r] = *(gf32x4p)(ok ? gb + (gy * gp.rs + gx * gp.ps + c * 4) : zero);
         }
     };
     auto store_tile = [&]() {
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradPara
 #pragma unroll 1
     for (; t < ntiles; t += P.nparts) {
         const bool more = (t + P.nparts < ntiles);
-        if (more) load_tile(t + P.nparts);
+        if (more && !(abl & 16)) load_tile(t + P.nparts);
         W3_TICK(0);
         // Running accumulators take every product: 12 roundings per tile row and tap, against 32 for an fp32 fma chain over
         // the same 32 pixels (single-layer error vs float64: tools/dbg_layer.py).
@@ -192,6 +205,7 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradPara
                 const bf16x8 xh = w3_tr_frag(xbase, off);
                 const bf16x8 xm = w3_tr_frag(xbase, W3_XT + off);
                 const bf16x8 xl = w3_tr_frag(xbase, 2 * W3_XT + off);
+                if (abl & 8) continue;
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, g[0], acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, g[2], acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, g[1], acc[tap], 0, 0, 0);
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad_s3_kernel(const WgradPara
         W3_TICK(1);
         __syncthreads();
         W3_TICK(2);
-        if (more) store_tile();
+        if (more && !(abl & 1)) store_tile();
         W3_TICK(3);
         __syncthreads();
         W3_TICK(4);
