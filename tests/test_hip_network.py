@@ -165,7 +165,7 @@ def test_train_step_adam_matches_oracle():
     assert solid.mean() > 0.8
     assert np.abs(d_eng[solid] - d_ora[solid]).max() < 5e-8, np.abs(d_eng[solid] - d_ora[solid]).max()
     assert np.abs(d_eng - d_ora).max() < 2.5e-4          # nobody moves by more than the three steps allow
-    assert np.abs(d_ora[solid]).min() > 1e-5             # and the solid ones really moved
+    assert np.median(np.abs(d_ora[solid])) > 1e-4        # and the solid ones really moved (about 3 steps of lr)
 
 
 @pytest.mark.parametrize("math", MATHS)
