@@ -1,6 +1,6 @@
 """One data-parallel rank on the REAL HIP engine (not a test module: started by tests/test_hip_parallel.py, one process
 per rank).  Ranks may share one GPU (gloo backend) or own one each (nccl = RCCL).  Usage:
-    RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/dp_worker.py <out_dir> <backend> <steps> <math>
+    RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/dp_worker.py <out_dir> <backend> <steps> <math> [dn|sr]
 Writes <out_dir>/rank<r>.npz with the flat parameters after every step, the all-reduced flat gradients of every step and
 the per-step local losses."""
 import os
@@ -21,21 +21,22 @@ import gen_common as gc  # noqa: E402
 BLOCKS, SHAPE, GLOBAL_B = 2, (40, 72), 4
 
 
-def build(seed):
-    from xmm_superres_denoise.models import GeneratorRRDB_DN
-    m = GeneratorRRDB_DN(1, 1, 32, BLOCKS)
-    st = gc.make_state("dn", 32, BLOCKS, seed)
+def build(seed, kind="dn"):
+    from xmm_superres_denoise.models import GeneratorRRDB_DN, GeneratorRRDB_SR
+    m = GeneratorRRDB_DN(1, 1, 32, BLOCKS) if kind == "dn" else GeneratorRRDB_SR(1, 1, 32, BLOCKS, num_upsample=1)
+    st = gc.make_state(kind, 32, BLOCKS, seed, last_bias=0.2 if kind == "sr" else None)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()})
     return m
 
 
-def global_batch():
+def global_batch(kind="dn"):
+    s = 2 if kind == "sr" else 1
     x = gc.make_input((GLOBAL_B, 1) + SHAPE, 501)
-    t = gc.make_input((GLOBAL_B, 1) + SHAPE, 502)
+    t = gc.make_input((GLOBAL_B, 1, SHAPE[0] * s, SHAPE[1] * s), 502)
     return torch.from_numpy(x), torch.from_numpy(t)
 
 
-def run(out_dir, backend, steps, math):
+def run(out_dir, backend, steps, math, kind="dn"):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     ndev = torch.cuda.device_count()
     dev = torch.device("cuda", rank % ndev if backend != "nccl" else rank)
@@ -46,9 +47,9 @@ def run(out_dir, backend, steps, math):
         dist.init_process_group(backend, rank=rank, world_size=world)
     from xmm_superres_denoise.parallel import DataParallelTrainer
     # rank > 0 starts from different weights on purpose: the trainer's construction-time broadcast must fix that
-    model = build(300 + rank).to(dev).set_math(math)
+    model = build(300 + rank, kind).to(dev).set_math(math)
     tr = DataParallelTrainer(model, lr=1e-3)
-    x, t = global_batch()
+    x, t = global_batch(kind)
     xs, ts = tr.shard(x).to(dev), tr.shard(t).to(dev)
     params, grads, losses = [], [], []
     for _ in range(steps):
@@ -61,4 +62,4 @@ def run(out_dir, backend, steps, math):
 
 
 if __name__ == "__main__":
-    run(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4])
+    run(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "dn")

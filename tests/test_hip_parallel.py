@@ -25,13 +25,13 @@ def _free_port():
     return p
 
 
-def _launch(out_dir, world, backend, steps, math):
+def _launch(out_dir, world, backend, steps, math, kind="dn"):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(out_dir), backend, str(steps), math],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(out_dir), backend, str(steps), math, kind],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:
@@ -47,20 +47,21 @@ def _launch(out_dir, world, backend, steps, math):
     return [np.load(os.path.join(out_dir, f"rank{r}.npz")) for r in range(world)]
 
 
-@pytest.mark.parametrize("math", ["bf16x6", "fp32"])
-def test_two_ranks_on_hip_engine_match_single_process_full_batch(tmp_path, math):
+@pytest.mark.parametrize("math,kind", [("bf16x6", "dn"), ("fp32", "dn"), ("bf16x6", "sr")])
+def test_two_ranks_on_hip_engine_match_single_process_full_batch(tmp_path, math, kind):
+    """kind "sr": the per-GPU share of BASELINE configs[3] (SR train, data parallel), two ranks"""
     import dp_worker as W
     from xmm_superres_denoise.parallel import DataParallelTrainer
     steps, world = 2, 2
     backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
-    res = _launch(tmp_path, world, backend, steps, math)
+    res = _launch(tmp_path, world, backend, steps, math, kind)
     # (1) replicas stay bit-identical (same all-reduced gradient, same Adam update on every rank)
     assert np.array_equal(res[0]["params"], res[1]["params"])
     assert np.array_equal(res[0]["grads"], res[1]["grads"])
     # (2) and equal a single-process step on the full batch: rank 0's initial weights (broadcast), whole global batch
-    model = W.build(300).cuda().set_math(math)
+    model = W.build(300, kind).cuda().set_math(math)
     tr = DataParallelTrainer(model, lr=1e-3)
-    x, t = W.global_batch()
+    x, t = W.global_batch(kind)
     x, t = x.cuda(), t.cuda()
     for s in range(steps):
         loss = float(tr.train_step(x, t))
