@@ -114,7 +114,7 @@ MATHS = {
     # mode: (dtype label, kernel name, fp32-class?)
     "fp32": ("f32", "conv3x3_mfma_kernel<*,false>", True),
     "bf16x6": ("f32 (exact 3-term bf16 split, 6 bf16 MFMA products per fp32 product, single-rounding f32 accumulate, f32 planes)",
-               "conv3x3_s3_kernel", True),
+               "conv3x3_s3x_kernel", True),
     "bf16x3": ("bf16x3 (hi+lo split MFMA, f32 accumulate, f32 planes)", "conv3x3_mfma_kernel<*,true>", False),
     "bf16x3_p16": ("bf16x3 (hi+lo split MFMA, f32 accumulate, hi|lo bf16 planes)", "conv3x3_p16_kernel", False),
 }

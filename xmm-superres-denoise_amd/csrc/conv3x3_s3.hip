@@ -34,6 +34,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "xsd_kernels.h"
+#include "xsd_split.h"
 
 namespace xsd {
 
@@ -64,21 +65,7 @@ constexpr int T3_WSLOTS = 9 * 64 * 2;               // float4 slots of an fp32 h
 constexpr int T3_WR = (T3_WSLOTS + T3_THREADS - 1) / T3_THREADS;   // 3
 
 // exact 3-term split of 4 fp32 values into packed bf16 pairs
-__device__ __forceinline__ void s3_split4(const f32x4& a, u32x2& hi, u32x2& mid, u32x2& lo)
-{
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {
-        const float x0 = a[2 * w], x1 = a[2 * w + 1];
-        const unsigned int h0 = __builtin_bit_cast(unsigned short, (__bf16)x0), h1 = __builtin_bit_cast(unsigned short, (__bf16)x1);
-        const float r0 = x0 - __builtin_bit_cast(float, h0 << 16), r1 = x1 - __builtin_bit_cast(float, h1 << 16);
-        const unsigned int m0 = __builtin_bit_cast(unsigned short, (__bf16)r0), m1 = __builtin_bit_cast(unsigned short, (__bf16)r1);
-        const float q0 = r0 - __builtin_bit_cast(float, m0 << 16), q1 = r1 - __builtin_bit_cast(float, m1 << 16);
-        const unsigned int l0 = __builtin_bit_cast(unsigned short, (__bf16)q0), l1 = __builtin_bit_cast(unsigned short, (__bf16)q1);
-        hi[w] = h0 | (h1 << 16);
-        mid[w] = m0 | (m1 << 16);
-        lo[w] = l0 | (l1 << 16);
-    }
-}
+__device__ __forceinline__ void s3_split4(const f32x4& a, u32x2& hi, u32x2& mid, u32x2& lo) { split3_f32x4(a, hi, mid, lo); }   // xsd_split.h
 
 __global__ __launch_bounds__(T3_THREADS, 2) void conv3x3_s3_kernel(const ConvParams P)
 {

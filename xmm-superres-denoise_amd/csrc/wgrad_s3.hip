@@ -11,6 +11,7 @@
 // images [pixel][32 x bf16] (X_hi, X_mid, X_lo over the 6 x 34 halo, G_hi, G_mid, G_lo; 63,744 B) read with the
 // transposing ds_read_b64_tr_b16.  Fixed-order two-stage reduction (wgrad_reduce_kernel): bitwise reproducible, no atomics.
 #include "xsd_kernels.h"
+#include "xsd_split.h"
 
 namespace xsd {
 
@@ -35,21 +36,7 @@ constexpr int W3_G_OFF = 3 * W3_XT;                                   // 39,168
 constexpr int W3_LDS_BYTES = (W3_G_OFF + 3 * W3_GT) > W3_TH * 4096 ? (W3_G_OFF + 3 * W3_GT) : W3_TH * 4096;   // 63,744
 
 // exact 3-term split of 4 fp32 values into packed bf16 pairs
-__device__ __forceinline__ void w3_split4(const f32x4& a, u32x2& hi, u32x2& mid, u32x2& lo)
-{
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {
-        const float x0 = a[2 * w], x1 = a[2 * w + 1];
-        const unsigned int h0 = __builtin_bit_cast(unsigned short, (__bf16)x0), h1 = __builtin_bit_cast(unsigned short, (__bf16)x1);
-        const float r0 = x0 - __builtin_bit_cast(float, h0 << 16), r1 = x1 - __builtin_bit_cast(float, h1 << 16);
-        const unsigned int m0 = __builtin_bit_cast(unsigned short, (__bf16)r0), m1 = __builtin_bit_cast(unsigned short, (__bf16)r1);
-        const float q0 = r0 - __builtin_bit_cast(float, m0 << 16), q1 = r1 - __builtin_bit_cast(float, m1 << 16);
-        const unsigned int l0 = __builtin_bit_cast(unsigned short, (__bf16)q0), l1 = __builtin_bit_cast(unsigned short, (__bf16)q1);
-        hi[w] = h0 | (h1 << 16);
-        mid[w] = m0 | (m1 << 16);
-        lo[w] = l0 | (l1 << 16);
-    }
-}
+__device__ __forceinline__ void w3_split4(const f32x4& a, u32x2& hi, u32x2& mid, u32x2& lo) { split3_f32x4(a, hi, mid, lo); }   // xsd_split.h
 
 // 8 consecutive pixels (k = 8h + 0..7) of this lane's channel from a [pixel][32 x bf16] image
 __device__ __forceinline__ bf16x8 w3_tr_frag(const char* lds_lane_base, int byte_off)

@@ -123,6 +123,19 @@ static void take_conv(long long& off, int cout, int cin, long long& w, long long
     b = off; off += cout;
 }
 
+// bf16x6 conv: the default is the role-split kernel (8 MFMA + 4 staging waves, conv3x3_s3x.hip); the build flag
+// XSD_CONV_UNIFIED (A/B builds, `make unified`) selects the 8-wave kernel in which every wave stages and multiplies
+// (conv3x3_s3.hip).  In the diagnostic library ablate bit 20 picks the other one.
+static hipError_t launch_conv_bf16x6(int ablate, const ConvParams& p, hipStream_t s)
+{
+#ifdef XSD_CONV_UNIFIED
+    const bool unified = !(ablate & (1 << 20));
+#else
+    const bool unified = (ablate & (1 << 20)) != 0;
+#endif
+    return unified ? launch_conv3x3_s3(p, s) : launch_conv3x3_s3x(p, s);
+}
+
 static hipError_t prof_launch(xsd_engine* e, int klass, double flop, double bytes, hipStream_t s, const std::function<hipError_t()>& f)
 {
     if (!e->prof) return f();
@@ -254,7 +267,7 @@ struct Builder {
             p.dbg = eng->dbg;
             p.ablate = eng->ablate;
             p.zero = eng->zero_page;
-            return prof_launch(eng, 0, flop, bytes, s, [&]() { return eng->math == 3 ? launch_conv3x3_s3(p, s) : eng->math == 2 ? launch_conv3x3_p16(p, s) : launch_conv3x3_mfma(p, eng->math, s); });
+            return prof_launch(eng, 0, flop, bytes, s, [&]() { return eng->math == 3 ? launch_conv_bf16x6(eng->ablate, p, s) : eng->math == 2 ? launch_conv3x3_p16(p, s) : launch_conv3x3_mfma(p, eng->math, s); });
         };
     }
     // wgrad + fixed-order reduce into the flat gradient vector
@@ -907,7 +920,7 @@ static hipError_t run_conv(xsd_engine* e, ConvParams& p, hipStream_t s)
 {
     p.zero = e->zero_page;
     for (int i = 0; i < (p.n_out > 1 ? p.n_out : p.n_in); ++i) p.wstep[i] = p.wpanel + (long long)i * PANEL_FLOATS;
-    if (e->math == 3) return launch_conv3x3_s3(p, s);
+    if (e->math == 3) return launch_conv_bf16x6(e->ablate, p, s);
     if (e->math == 2) return launch_conv3x3_p16(p, s);
     return launch_conv3x3_mfma(p, e->math, s);
 }

@@ -1,0 +1,53 @@
+// xsd_split.h -- the exact 3-term bf16 split of math mode 3 ("bf16x6"), shared by conv3x3_s3*.hip and wgrad_s3.hip.
+// x = hi + mid + lo exactly (each term the round-to-nearest-even bf16 of what the previous terms left), four fp32 values
+// -> three word pairs of packed bf16.  Written over the natural pairs so that hipcc emits 22 VALU instructions per float4
+// (v_cvt_pk_bf16_f32, v_lshlrev/v_and to widen, v_sub_f32 for the residuals); the element-wise form it replaced compiled
+// to 32 (cross-paired converts, v_mov copies and SDWA merges).  The residual subtractions are single v_sub_f32 through
+// inline asm ON PURPOSE: left to itself hipcc packs them into v_pk_add_f32, and packed-f32 VALU beside running MFMAs
+// costs ~13 extra cycles per instruction on this chip (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
+#pragma once
+
+namespace xsd {
+
+typedef float split_f32x4 __attribute__((ext_vector_type(4)));
+typedef float split_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 split_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int split_u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float split_sub(float a, float b)
+{
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ void split3_pair(split_f32x2 x, unsigned int& h, unsigned int& m, unsigned int& l)
+{
+    h = __builtin_bit_cast(unsigned int, __builtin_convertvector(x, split_bf16x2));
+    split_f32x2 hf;
+    hf[0] = __builtin_bit_cast(float, h << 16);
+    hf[1] = __builtin_bit_cast(float, h & 0xffff0000u);
+    split_f32x2 r;
+    r[0] = split_sub(x[0], hf[0]);
+    r[1] = split_sub(x[1], hf[1]);
+    m = __builtin_bit_cast(unsigned int, __builtin_convertvector(r, split_bf16x2));
+    split_f32x2 mf;
+    mf[0] = __builtin_bit_cast(float, m << 16);
+    mf[1] = __builtin_bit_cast(float, m & 0xffff0000u);
+    split_f32x2 q;
+    q[0] = split_sub(r[0], mf[0]);
+    q[1] = split_sub(r[1], mf[1]);
+    l = __builtin_bit_cast(unsigned int, __builtin_convertvector(q, split_bf16x2));
+}
+
+__device__ __forceinline__ void split3_f32x4(const split_f32x4& a, split_u32x2& hi, split_u32x2& mid, split_u32x2& lo)
+{
+    unsigned int h0, m0, l0, h1, m1, l1;
+    split3_pair(a.xy, h0, m0, l0);
+    split3_pair(a.zw, h1, m1, l1);
+    hi[0] = h0; hi[1] = h1;
+    mid[0] = m0; mid[1] = m1;
+    lo[0] = l0; lo[1] = l1;
+}
+
+} // namespace xsd
