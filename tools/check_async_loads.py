@@ -1,9 +1,10 @@
-"""ISA check for the hand-counted prefetch of conv3x3_s3x's staging waves (csrc/conv3x3_s3x.hip).
+"""ISA check for the hand-counted prefetch of the staging waves of the role-split kernels (csrc/conv3x3_s3x.hip,
+csrc/wgrad_s3x.hip).
 
 The staging loop issues its global loads and their `s_waitcnt vmcnt(14)` from inline asm, so hipcc does not know that a
 load's destination registers are written asynchronously.  That is only correct if, in the generated code,
-  * the loop holds exactly 15 asm loads, each group of m loads behind one asm wait `vmcnt(15 - m)`, and no other
-    vector-memory instruction (anything else would shift the hand-made count),
+  * the loop holds exactly N asm loads (15 for the conv, 11 for the weight gradient), each group of m loads behind one asm wait
+    `vmcnt(N - m)` -- and no other vector-memory instruction (anything else would shift the hand-made count),
   * the destination registers of a load are touched nowhere in the loop except between its group's wait and the last
     load of the group, and not after its own reload was issued (no copy made while the load is in flight, no reuse
     as a temporary).
@@ -16,8 +17,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "xmm-superres-denoise_amd", "csrc", "conv3x3_s3x.hip")
-NLOADS = 15
+CSRC = os.path.join(ROOT, "xmm-superres-denoise_amd", "csrc")
+KERNELS = (("conv3x3_s3x.hip", 15), ("wgrad_s3x.hip", 11))     # source, counted loads per pass of the staging loop
 
 
 def regs_of(tok):
@@ -30,7 +31,7 @@ def regs_of(tok):
     return out
 
 
-def check(asm_text):
+def check(asm_text, NLOADS=15):
     lines = asm_text.splitlines()
     heads = [i for i, l in enumerate(lines) if "Inner Loop Header" in l]
     # the staging loop is the one that holds the asm waits
@@ -44,7 +45,7 @@ def check(asm_text):
         end = max(j for j, l in enumerate(lines) if re.search(r"s_c?branch\w*\s+(\S+)", l) and l.split()[-1] in labels)
         loops.append((start, end))
     cand = [(a, b) for a, b in loops if sum("buffer_load_dwordx4" in l for l in lines[a:b]) == NLOADS]
-    assert len(cand) == 1, "staging loop not found (loops with 15 buffer loads: %d)" % len(cand)
+    assert len(cand) == 1, "staging loop not found (loops with %d buffer loads: %d)" % (NLOADS, len(cand))
     a, b = cand[0]
     body = [l.split(";")[0].strip() for l in lines[a:b + 1]]
     body = [l for l in body if l and not l.startswith(".") and not l.endswith(":")]
@@ -109,12 +110,13 @@ def check(asm_text):
 
 def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "k.s")
-        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",   # the flags of csrc/Makefile
-                        "-S", "--cuda-device-only", SRC, "-o", out], check=True, stderr=subprocess.DEVNULL)
-        n = check(open(out).read())
-    print("conv3x3_s3x staging loop: %d instructions, %d counted loads, destinations private to their windows" % (n, NLOADS))
+    for src, nloads in KERNELS:
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "k.s")
+            subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",   # the flags of csrc/Makefile
+                            "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out], check=True, stderr=subprocess.DEVNULL)
+            n = check(open(out).read(), nloads)
+        print("%s staging loop: %d instructions, %d counted loads, destinations private to their windows" % (src, n, nloads))
 
 
 if __name__ == "__main__":

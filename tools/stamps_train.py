@@ -23,8 +23,8 @@ print(math, 'B', B, 'train step ms', t0.elapsed_time(t1))
 names = ['prologue', 'prefetch issue', 'MFMA loop', 'epilogue', 'wait+barrier1', 'split+write+barrier2']
 tot = sum(v[:6])
 print(' conv: half-steps', v[6])
-for n, c in zip(names, v[:6]): print(f'  {n:24s} {c / max(v[6], 1):10.0f} cycles/item  {100 * c / max(tot, 1):5.1f}%')
-wn = ['issue loads', 'MFMA loop', 'barrier1', 'wait loads+split+write', 'barrier2']
+for n, c in zip(names, v[:6]): print(f'  {n:52s} {c / max(v[6], 1):10.0f} cycles/item  {100 * c / max(tot, 1):5.1f}%')
+wn = ['issue loads | staging rounds (role-split)', 'MFMA loop', 'barrier1 | MFMA wave at barrier', 'wait loads+split+write | staging wave at barrier', 'barrier2']
 tot = sum(v[8:13])
 print(' wgrad: tiles', v[13])
-for n, c in zip(wn, v[8:13]): print(f'  {n:24s} {c / max(v[13], 1):10.0f} cycles/tile  {100 * c / max(tot, 1):5.1f}%')
+for n, c in zip(wn, v[8:13]): print(f'  {n:52s} {c / max(v[13], 1):10.0f} cycles/tile  {100 * c / max(tot, 1):5.1f}%')

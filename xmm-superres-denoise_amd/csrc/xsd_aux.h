@@ -43,6 +43,7 @@ hipError_t launch_pack_weights_s3(const float* params, const PackDesc* descs_dev
 hipError_t launch_conv3x3_s3(const ConvParams& p, hipStream_t stream);
 hipError_t launch_conv3x3_s3x(const ConvParams& p, hipStream_t stream);
 hipError_t launch_wgrad_s3(const WgradParams& p, hipStream_t stream);
+hipError_t launch_wgrad_s3x(const WgradParams& p, hipStream_t stream);
 hipError_t launch_plane_convert(const float* in, float* out, long long npix, int to_p16, hipStream_t s);
 hipError_t launch_conv3x3_p16(const ConvParams& p, hipStream_t stream);
 hipError_t launch_wgrad_p16(const WgradParams& p, hipStream_t stream);

@@ -136,6 +136,22 @@ static hipError_t launch_conv_bf16x6(int ablate, const ConvParams& p, hipStream_
     return unified ? launch_conv3x3_s3(p, s) : launch_conv3x3_s3x(p, s);
 }
 
+// bf16x6 weight gradient, same switch: role-split kernel (one workgroup per CU, `nparts` partial sums) or the unified one
+// (two workgroups per CU, 2 x nparts partials).
+static bool wgrad_bf16x6_unified(int ablate)
+{
+#ifdef XSD_CONV_UNIFIED
+    return !(ablate & (1 << 21));
+#else
+    return (ablate & (1 << 21)) != 0;
+#endif
+}
+static int wgrad_bf16x6_parts(int ablate, int nparts) { return wgrad_bf16x6_unified(ablate) ? 2 * nparts : nparts; }
+static hipError_t launch_wgrad_bf16x6(int ablate, const WgradParams& p, hipStream_t s)
+{
+    return wgrad_bf16x6_unified(ablate) ? launch_wgrad_s3(p, s) : launch_wgrad_s3x(p, s);
+}
+
 static hipError_t prof_launch(xsd_engine* e, int klass, double flop, double bytes, hipStream_t s, const std::function<hipError_t()>& f)
 {
     if (!e->prof) return f();
@@ -279,7 +295,7 @@ struct Builder {
         memset(&wp, 0, sizeof(wp));
         wp.B = B; wp.H = H << level; wp.W = W << level;
         wp.tilesX = (wp.W + TILE_W - 1) / TILE_W; wp.tilesY = (wp.H + TILE_H - 1) / TILE_H;
-        wp.n_in = (int)xs.size(); wp.n_g = (int)gs.size(); wp.nparts = e->math == 3 ? 2 * e->nparts : e->nparts;   // mode 3: two workgroups per CU
+        wp.n_in = (int)xs.size(); wp.n_g = (int)gs.size(); wp.nparts = e->math == 3 ? wgrad_bf16x6_parts(e->ablate, e->nparts) : e->nparts;
         for (size_t i = 0; i < xs.size(); ++i) wp.x[i] = xs[i];
         for (size_t i = 0; i < gs.size(); ++i) wp.g[i] = gs[i];
         WgradReduceParams rp;
@@ -295,7 +311,7 @@ struct Builder {
             rp.partial = eng->wg_partial; rp.bias_partial = eng->wg_bias_partial;
             rp.dw = eng->b_grads + w_off; rp.db = eng->b_grads + b_off;
             wp.zero = eng->zero_page; wp.ablate = eng->ablate; wp.dbg = eng->dbg; rp.p16 = eng->math == 2;
-            hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return eng->math == 3 ? launch_wgrad_s3(wp, s) : eng->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, eng->math, s); });
+            hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return eng->math == 3 ? launch_wgrad_bf16x6(eng->ablate, wp, s) : eng->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, eng->math, s); });
             if (err != hipSuccess) return err;
             return launch_wgrad_reduce(rp, s);
         });
@@ -991,11 +1007,11 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
     hipError_t err = run_conv(e, p, s);
     if (err == hipSuccess) {
         WgradParams wp; memset(&wp, 0, sizeof(wp));
-        wp.B = B; wp.H = H; wp.W = W; wp.tilesX = p.tilesX; wp.tilesY = p.tilesY; wp.n_in = n_in; wp.n_g = 1; wp.nparts = e->math == 3 ? 2 * e->nparts : e->nparts;
+        wp.B = B; wp.H = H; wp.W = W; wp.tilesX = p.tilesX; wp.tilesY = p.tilesY; wp.n_in = n_in; wp.n_g = 1; wp.nparts = e->math == 3 ? wgrad_bf16x6_parts(e->ablate, e->nparts) : e->nparts;
         for (int i = 0; i < n_in; ++i) wp.x[i] = b.std_in(ins[i], 0);
         wp.g[0] = b.std_in(g, 0);
         wp.partial = e->wg_partial; wp.bias_partial = e->wg_bias_partial; wp.zero = e->zero_page;
-        err = e->math == 3 ? launch_wgrad_s3(wp, s) : e->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, e->math, s);
+        err = e->math == 3 ? launch_wgrad_bf16x6(e->ablate, wp, s) : e->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, e->math, s);
         if (err == hipSuccess) {
             WgradReduceParams rp; memset(&rp, 0, sizeof(rp));
             rp.partial = e->wg_partial; rp.bias_partial = e->wg_bias_partial; rp.nparts = wp.nparts; rp.n_in = n_in; rp.n_g = 1;
