@@ -495,6 +495,9 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
         for (int q = 0; q < 6; ++q) atomicAdd(&P.dbg[q], st[q]);
         atomicAdd(&P.dbg[6], (unsigned long long)items);
     }
+    if (stamp && tid == 64 * (X3_LWAVES + X3_MWAVES - 1)) {   // the youngest MFMA wave: slots 13..15 = MFMA walk, epilogue, barrier A
+        atomicAdd(&P.dbg[13], st[2]); atomicAdd(&P.dbg[14], st[3]); atomicAdd(&P.dbg[15], st[4]);
+    }
 #endif
 }
 
