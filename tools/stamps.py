@@ -20,6 +20,7 @@ names=['prologue','prefetch issue','MFMA loop','epilogue','wait+barrier1','split
 tot=sum(v[:6])
 print(math,'B',B,'fwd ms',t0.elapsed_time(t1),'items',v[6])
 for n,c in zip(names,v[:6]): print(f'  {n:24s} {c/max(v[6],1):10.0f} cycles/item  {100*c/tot:5.1f}%')
+if v[7]: print(f'  in-kernel clock (stamped cycles / s_memrealtime at 100 MHz): {tot/v[7]*0.1:.3f} GHz')
 if any(v[8:13]):
     print('  staging wave 0 (role-split kernel):')
     for n,c in zip(['input rounds','weight rounds','wait barrier A','weight write','barrier B + bookkeeping'],v[8:13]): print(f'  {n:24s} {c/max(v[6],1):10.0f} cycles/item')

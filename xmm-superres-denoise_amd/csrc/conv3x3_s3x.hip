@@ -450,6 +450,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
 
 #ifdef XSD_DIAG   // phase stamps (diagnostic library variant only; tools/stamps.py): accumulated shader cycles per phase
     unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz: in-kernel clock = stamped cycles / this
     unsigned long long t0 = __builtin_readcyclecounter();
     const bool stamp = P.dbg != nullptr;
 #define X3_TICK(i) do { if (stamp) { const unsigned long long t_ = __builtin_readcyclecounter(); st[i] += t_ - t0; t0 = t_; } } while (0)
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
 #pragma unroll
         for (int q = 0; q < 6; ++q) atomicAdd(&P.dbg[q], st[q]);
         atomicAdd(&P.dbg[6], (unsigned long long)items);
+        atomicAdd(&P.dbg[7], __builtin_amdgcn_s_memrealtime() - rt0);
     }
     if (stamp && tid == 64 * (X3_LWAVES + X3_MWAVES - 1)) {   // the youngest MFMA wave: slots 13..15 = MFMA walk, epilogue, barrier A
         atomicAdd(&P.dbg[13], st[2]); atomicAdd(&P.dbg[14], st[3]); atomicAdd(&P.dbg[15], st[4]);
