@@ -115,12 +115,14 @@ MATHS = {
     "fp32": ("f32", "conv3x3_mfma_kernel<*,false>", True),
     "bf16x6": ("f32 (exact 3-term bf16 split, 6 bf16 MFMA products per fp32 product, single-rounding f32 accumulate, f32 planes)",
                "conv3x3_s3x_kernel", True),
+    "f16x3": ("f32 (2-term fp16 split of power-of-two-scaled operands, 3 fp16 MFMA products per fp32 product, single-rounding f32 accumulate, f32 planes)",
+              "conv3x3_h2x_kernel", True),
     "bf16x3": ("bf16x3 (hi+lo split MFMA, f32 accumulate, f32 planes)", "conv3x3_mfma_kernel<*,true>", False),
     "bf16x3_p16": ("bf16x3 (hi+lo split MFMA, f32 accumulate, hi|lo bf16 planes)", "conv3x3_p16_kernel", False),
 }
 DEFAULT_MATH = "bf16x6"
-MATH_PRODUCTS = {"bf16x6": 6, "bf16x3": 3, "bf16x3_p16": 3}   # bf16 MFMAs per fp32 product
-MATH_BOUND = {"bf16x6": "mfma", "bf16x3": "hbm", "bf16x3_p16": "hbm"}  # binding roofline of the conv kernel
+MATH_PRODUCTS = {"bf16x6": 6, "f16x3": 3, "bf16x3": 3, "bf16x3_p16": 3}   # bf16 MFMAs per fp32 product
+MATH_BOUND = {"bf16x6": "mfma", "f16x3": "mfma", "bf16x3": "hbm", "bf16x3_p16": "hbm"}  # binding roofline of the conv kernel
 
 
 def self_launch(args) -> int:

@@ -21,14 +21,14 @@ def _relmax(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-MATHS = ["fp32", "bf16x6", "bf16x3", "bf16x3_p16"]
-FP32_CLASS = ("fp32", "bf16x6")   # held to the flip-aware comparison: only rows named by a flip candidate may deviate
+MATHS = ["fp32", "bf16x6", "f16x3", "bf16x3", "bf16x3_p16"]
+FP32_CLASS = ("fp32", "bf16x6", "f16x3")   # held to the flip-aware comparison: only rows named by a flip candidate may deviate
 # gradient tolerances (see util_hip.assert_grad_close).  fp32-class modes: 2e-4 of the tensor's largest entry on every row
 # that has no flip candidate (north_star: 1e-3).  The 16-bit modes (hi+lo bf16 significands; extras, never the headline)
 # are tolerance-only: 3 x 2^-16 per product, P16 additionally rounds every stored activation / gradient plane to 16 bits,
 # which is why its input-gradient (it passes through every layer's gradient plane) gets 5e-3.
-TIGHT = {"fp32": 2e-4, "bf16x6": 2e-4, "bf16x3": 5e-4, "bf16x3_p16": 1e-3}
-DX_TIGHT = {"fp32": 4e-4, "bf16x6": 4e-4, "bf16x3": 1e-3, "bf16x3_p16": 5e-3}
+TIGHT = {"fp32": 2e-4, "bf16x6": 2e-4, "f16x3": 2e-4, "bf16x3": 5e-4, "bf16x3_p16": 1e-3}
+DX_TIGHT = {"fp32": 4e-4, "bf16x6": 4e-4, "f16x3": 4e-4, "bf16x3": 1e-3, "bf16x3_p16": 5e-3}
 
 
 def _report_flips(tag, before):

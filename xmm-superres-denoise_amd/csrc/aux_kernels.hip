@@ -418,6 +418,31 @@ __global__ void pack_weights_s3_kernel(const float* params, const PackDesc* desc
     }
 }
 
+// math mode 4 (f16x3): max |x| of a plane view / of a flat buffer into a slot (atomic max of the float bits; the slot is zeroed by the
+// caller).  Used for planes written by kernels that do not report it themselves (edge layers, test hooks) and for the packed
+// weight buffers; the consumers scale their operands into the fp16 range with it (xsd_split.h, scale_for_amax).
+__global__ void plane_amax_kernel(PlaneIn v, int B, int H, int W, float* slot)
+{
+    const long long total = (long long)B * H * W * 8;        // (pixel, channel quad)
+    float m = 0.f;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(g & 7);
+        long long pix = g >> 3;
+        const int x = (int)(pix % W); pix /= W;
+        const int y = (int)(pix % H);
+        const int b = (int)(pix / H);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(v.p + (long long)b * v.bs + (long long)y * v.rs + (long long)x * v.ps + q * 4);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(t[0]), fabsf(t[1]))), fmaxf(fabsf(t[2]), fabsf(t[3])));
+    }
+    atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(m));
+}
+__global__ void buffer_amax_kernel(const float* v, long long n, float* slot)
+{
+    float m = 0.f;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(v[g]));
+    atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(m));
+}
+
 // fp32 plane <-> P16 plane (test hooks / debugging): thread = (pixel, 4-channel quad)
 __global__ void plane_to_p16_kernel(const float* in, float* out, long long npix)
 {
@@ -648,6 +673,16 @@ hipError_t launch_pack_weights_s3(const float* params, const PackDesc* descs_dev
                                   hipStream_t s)
 {
     hipLaunchKernelGGL(pack_weights_s3_kernel, dim3(36, ndesc), dim3(256), 0, s, params, descs_dev, fwd, bwd);
+    return hipGetLastError();
+}
+hipError_t launch_plane_amax(const PlaneIn& v, int B, int H, int W, float* slot, hipStream_t s)
+{
+    hipLaunchKernelGGL(plane_amax_kernel, dim3(grid_for((long long)B * H * W * 8, 256)), dim3(256), 0, s, v, B, H, W, slot);
+    return hipGetLastError();
+}
+hipError_t launch_buffer_amax(const float* v, long long n, float* slot, hipStream_t s)
+{
+    hipLaunchKernelGGL(buffer_amax_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, s, v, n, slot);
     return hipGetLastError();
 }
 hipError_t launch_plane_convert(const float* in, float* out, long long npix, int to_p16, hipStream_t s)

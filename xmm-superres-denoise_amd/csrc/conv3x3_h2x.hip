@@ -1,26 +1,17 @@
-// conv3x3_s3x.hip -- math mode 3 ("bf16x6"): the 3x3 conv (forward + input-gradient) over fp32 feature planes with
-// fp32-CLASS arithmetic on the bf16 matrix cores; ROLE-SPLIT workgroup: 8 MFMA waves + 4 staging waves.
+// conv3x3_h2x.hip -- math mode 4 ("f16x3"): the 3x3 conv (forward + input-gradient) over fp32 feature planes with
+// fp32-CLASS arithmetic on the fp16 matrix cores at HALF the matrix work of mode 3; role-split workgroup as in
+// conv3x3_s3x.hip (4 staging + 8 MFMA waves; read that file for the structure, the counted prefetch and the LDS images).
 // Reference layers: nn.Conv2d(32k -> 32, 3, 1, 1) of rrdb_blocks.py:27-31, generator_rrdb.py:38-44,95,101 (fp32) and
 // their autograd input-gradients.
 //
-// Arithmetic: as conv3x3_s3.hip (exact 3-term bf16 split of both operands, six bf16 MFMA products per fp32 product,
-// hi*hi in one accumulator and the five cross products in a second one, MFMA single-rounding accumulation).
-//
-// Why roles.  In conv3x3_s3.hip every wave does everything, in order: a wave that is blocked issuing a global load or a
-// store, or that runs its share of the fp32 -> 3 x bf16 conversion, issues no MFMA meanwhile.  Here the two kinds of work
-// live in different waves of the same SIMD, where the hardware overlaps them (MFMA and VALU/VMEM pipes are separate):
-//   * waves 0..3 (one per SIMD) stage: buffer_load the next-but-one input half-tile and weight half-panel as fp32 into
-//     registers (15 loads in flight per wave, hand-counted waits), split what arrived a half-step earlier and write it
-//     to LDS: the input into the other of two buffers while the MFMA waves multiply the current one, the weights (kept
-//     split in registers) between the two barriers that end a half-step (single 27,648-B buffer), which leaves only LDS
-//     writes in that window;
-//   * waves 4..11 (two per SIMD) multiply: tile rows 2w, 2w+1 of the 16 x 32 tile; their stream is ds_read_b128 + v_mfma
-//     (63 + 108 per half-step, fragments reused across the two rows), plus the epilogue at the end of a tile whose
-//     stores are dripped into the next half-step's walk.
-// Three waves per SIMD -> 168 registers per wave.  LDS images, swizzle, descriptors, trash page: conv3x3_s3.hip.
-// What made it pay (each measured with the in-kernel stamps of the diagnostic build): no packed-f32
-// VALU beside the MFMAs (csrc/Makefile), an 22-instruction split, staging rounds without address arithmetic or
-// branches, LDS writes that are ds_write and not flat stores, counted waits instead of hipcc's vmcnt(0), deferred stores.
+// Arithmetic.  Each operand tensor is scaled by a power of two chosen from its max |x| (written by the kernel that produced
+// it, OutDesc::amax / plane_amax_kernel; the weights' by the pack kernel) so that it fits the fp16 range with full
+// precision, and split into two fp16 terms x*s = h + l*2^-11 (22-23 significant bits, xsd_split.h).  A product is
+// h*h (first accumulator) + (h*l + l*h) (second accumulator, weighted 2^-11 in the epilogue): three
+// v_mfma_f32_32x32x16_f16 instead of the six bf16 ones of mode 3; the MFMA sums its 16 products and the fp32 accumulator
+// exactly and rounds once (tools/mfma_probe_f16.hip).  The epilogue undoes the scales (exact) and reports max |result| of
+// the plane it writes.  Dropped: l*l (2^-22 relative) and the operands' last 1-2 bits; measured against float64 in
+// tests/test_hip_precision.py next to mode 3, the exact-fp32 mode and torch's fp32.
 #include <cstdlib>
 #include <type_traits>
 #include "xsd_kernels.h"
@@ -30,7 +21,7 @@ namespace xsd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) f32x4* x3_gload_p;
 typedef __attribute__((address_space(1))) f32x4* x3_gstore_p;
@@ -44,10 +35,13 @@ constexpr int X3_ROWS = 16;
 constexpr int X3_PX = (X3_ROWS + 2) * HALO_W;       // 612 halo pixels
 constexpr int X3_SINK = X3_PX * 32;                 // 19,584: each term image ends with a 512-B sink
 constexpr int X3_XT = X3_SINK + 512;                // 20,096 B per term image
-constexpr int X3_XB = 3 * X3_XT;                    // 60,288 B per input buffer
+constexpr int X3_XB = 2 * X3_XT;                    // 40,192 B per input buffer (two term images)
 constexpr int X3_WOFF = 2 * X3_XB;                  // 120,576
-constexpr int X3_WSINK = S3_WH_BYTES;               // sink behind the weight buffer (2048 + 512 B)
-constexpr int X3_BIAS = X3_WOFF + S3_WH_BYTES + 3072; // 151,296
+constexpr int X3_WSINK = H2_WH_BYTES;               // sink behind each weight buffer (1024 + 512 B)
+constexpr int X3_WB = H2_WH_BYTES + 2048;           // 20,480 B per weight buffer incl. its sink: TWO of them fit here (the
+                                                    // three-term images of mode 3 leave no room), so a half-step ends
+                                                    // with one barrier instead of the barrier / weight write / barrier
+constexpr int X3_BIAS = X3_WOFF + 2 * X3_WB;        // 121,344
 constexpr int X3_DESC = X3_BIAS + 5 * 32 * 4;       // 151,936
 constexpr int X3_LDS_BYTES = X3_DESC + 16 * 8;      // 152,064
 constexpr int X3_ROWB = HALO_W * 32;                // 1088
@@ -56,9 +50,9 @@ constexpr int X3_XR = (X3_XSLOTS + X3_LT - 1) / X3_LT;     // 10
 constexpr int X3_WSLOTS = 9 * 64 * 2;               // 1152 float4 slots of an fp32 half-panel
 constexpr int X3_WR = (X3_WSLOTS + X3_LT - 1) / X3_LT;     // 5
 
-__device__ __forceinline__ void x3_split4(const f32x4& a, u32x2& hi, u32x2& mid, u32x2& lo) { split3_f32x4(a, hi, mid, lo); }   // xsd_split.h
+__device__ __forceinline__ void x3_split4(const f32x4& a, float s, u32x2& hi, u32x2& lo) { split2_f16x4(a, s, hi, lo); }   // xsd_split.h
 
-__global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParams P)
+__global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* w_lds = smem + X3_WOFF;
@@ -118,6 +112,24 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
     };
     const int rs0 = P.in[0].rs, ps0 = P.in[0].ps;
 
+    // operand scales (powers of two) from the max |x| of the input planes and of the weight panels; every wave computes the
+    // same values from the same slots (scalar loads)
+    float sx, sw, inv_sx, inv_sw;
+    {
+        float ax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {       // static indices: a runtime index into the kernel arguments costs a scratch copy
+            const float* ap = P.amax_in[i];
+            const float a = (i < n_in && ap) ? *ap : (i < n_in ? 1.f : 0.f);
+            ax = a > ax ? a : ax;
+        }
+        const float aw = P.amax_w ? *P.amax_w : 1.f;
+        ax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ax)));
+        sx = scale_for_amax(ax, inv_sx);
+        sw = scale_for_amax(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, aw))), inv_sw);
+    }
+    const float inv_s = inv_sx * inv_sw;      // undoes both scales in the epilogue (exact)
+
     if (loader) {
         // ============================ staging waves ============================
         // Staging slots of this thread: slot(r) = r*256 + lt -> halo pixel p = r*64 + (lt >> 2), channel quad q = lt & 3.
@@ -158,10 +170,8 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
                 xoff[r] = ok ? (gy * rs0 + gx * ps0 + (lt & 3) * 4) * 4 : OOR;
             }
         };
-        const int woff = lt * 16;
         f32x4 pin[X3_XR] = {};
         f32x4 pw[X3_WR] = {};
-        u32x2 wsh[X3_WR] = {}, wsm[X3_WR] = {}, wsl[X3_WR] = {};
         // descriptors are read from LDS (per lane) and made scalar again: uniform values belong in SGPRs
         auto uniform64 = [&](unsigned long long v) {
             const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
@@ -190,34 +200,35 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
         auto asm_load4 = [&](f32x4& dst, int off, const i32x4& rs) {
             asm volatile("buffer_load_dwordx4 %[d], %[o], %[r], 0 offen" : [d] "+v"(dst) : [o] "v"(off), [r] "s"(rs) : "memory");
         };
-        // same, and the split of the consumed value is finished first (its results pass through the statement)
-        auto asm_load4_after = [&](f32x4& dst, int off, const i32x4& rs, u32x2& a, u32x2& b, u32x2& c) {
-            asm volatile("buffer_load_dwordx4 %[d], %[o], %[r], 0 offen" : [d] "+v"(dst), "+v"(a), "+v"(b), "+v"(c) : [o] "v"(off), [r] "s"(rs) : "memory");
-        };
         auto asm_wait14 = [&](f32x4& v) { asm volatile("s_waitcnt vmcnt(14)" : "+v"(v) :: "memory"); };
         auto asm_wait13 = [&](f32x4& u, f32x4& v) { asm volatile("s_waitcnt vmcnt(13)" : "+v"(u), "+v"(v) :: "memory"); };
         auto load_x_round = [&](int r, const i32x4& rs) { asm_load4(pin[r], xoff[r], rs); };
         auto store_x_round = [&](int r, int xb) {   // xb: byte offset of the input buffer in LDS
-            u32x2 hi, mid, lo;
-            if (abl & 1) { hi[0] = __float_as_uint(pin[r][0]); hi[1] = __float_as_uint(pin[r][1]); mid = hi; lo[0] = __float_as_uint(pin[r][2]); lo[1] = __float_as_uint(pin[r][3]); }
-            else x3_split4(pin[r], hi, mid, lo);
+            u32x2 hi, lo;
+            if (abl & 1) { hi[0] = __float_as_uint(pin[r][0]); hi[1] = __float_as_uint(pin[r][1]); lo[0] = __float_as_uint(pin[r][2]); lo[1] = __float_as_uint(pin[r][3]); }
+            else x3_split4(pin[r], sx, hi, lo);
             char* d = smem + xb + xlds[r];
-            if (abl & 2) { asm volatile("" :: "v"(hi), "v"(mid), "v"(lo), "v"(d)); return; }
+            if (abl & 2) { asm volatile("" :: "v"(hi), "v"(lo), "v"(d)); return; }
             *reinterpret_cast<u32x2*>(d) = hi;
-            *reinterpret_cast<u32x2*>(d + X3_XT) = mid;
-            *reinterpret_cast<u32x2*>(d + 2 * X3_XT) = lo;
+            *reinterpret_cast<u32x2*>(d + X3_XT) = lo;
         };
-        auto load_w_round = [&](int r, const i32x4& rs) { asm_load4_after(pw[r], woff + r * (X3_LT * 16), rs, wsh[r], wsm[r], wsl[r]); };
-        auto store_w = [&]() {
-#pragma unroll
-            for (int r = 0; r < X3_WR; ++r) {
-                const int s = r * X3_LT + lt;
-                const int frag = s >> 7, ln = (s >> 1) & 63, sub = s & 1;   // frag = tap
-                char* d = w_lds + (s < X3_WSLOTS ? frag * 3 * 1024 + ln * 16 + sub * 8 : X3_WSINK + lane * 8);
-                *reinterpret_cast<u32x2*>(d) = wsh[r];
-                *reinterpret_cast<u32x2*>(d + 1024) = wsm[r];
-                *reinterpret_cast<u32x2*>(d + 2048) = wsl[r];
-            }
+        // (the lane offset of the weight loads is rebuilt from the lane id at each use: kept in a register across the loop
+        // it is spilled, and hipcc then waits vmcnt(0) for the scratch reload INSIDE the loop -- which drains the whole
+        // hand-counted prefetch; tools/check_async_loads.py rejects any such wait)
+        auto load_w_round = [&](int r, const i32x4& rs) {
+            unsigned int all = ~0u;
+            asm volatile("" : "+s"(all));
+            const int t = wid * 64 + (int)__builtin_amdgcn_mbcnt_hi(all, __builtin_amdgcn_mbcnt_lo(all, 0u));
+            asm_load4(pw[r], t * 16 + r * (X3_LT * 16), rs);
+        };
+        auto store_w_round = [&](int r, int wb) {   // wb: byte offset of the weight buffer in LDS
+            u32x2 hi, lo;
+            x3_split4(pw[r], sw, hi, lo);
+            const int s = r * X3_LT + lt;
+            const int frag = s >> 7, ln = (s >> 1) & 63, sub = s & 1;   // frag = tap
+            char* d = w_lds + wb + (s < X3_WSLOTS ? frag * 2 * 1024 + ln * 16 + sub * 8 : X3_WSINK + lane * 8);
+            *reinterpret_cast<u32x2*>(d) = hi;
+            *reinterpret_cast<u32x2*>(d + 1024) = lo;
         };
 
         // prologue: half-step 0 into LDS, half-step 1 into the staging registers
@@ -234,8 +245,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
 #pragma unroll
             for (int r = 0; r < X3_XR; ++r) { asm volatile("" : "+v"(pin[r])); store_x_round(r, 0); }
 #pragma unroll
-            for (int r = 0; r < X3_WR; ++r) { asm volatile("" : "+v"(pw[r])); x3_split4(pw[r], wsh[r], wsm[r], wsl[r]); }
-            store_w();
+            for (int r = 0; r < X3_WR; ++r) { asm volatile("" : "+v"(pw[r])); store_w_round(r, 0); }
         }
         Cur n1 = succ(cur);                 // same tile: a tile has at least two half-steps
         TileXY t1 = tcur;
@@ -275,28 +285,24 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
                 __builtin_amdgcn_sched_barrier(0);   // a pair at a time, in order (the wait counts depend on it)
             }
             X3_LTICK(0);
-            // weights of half-step it+1: split in registers now, written when the MFMA waves are done with the buffer
+            // weights of half-step it+1 -> the other weight buffer, the same way
+            const int wn = ((it + 1) & 1) * X3_WB;
 #pragma unroll
             for (int r = 0; r + 1 < X3_WR; r += 2) {
                 if (!(abl & 4)) asm_wait13(pw[r], pw[r + 1]);
-                x3_split4(pw[r], wsh[r], wsm[r], wsl[r]);
-                x3_split4(pw[r + 1], wsh[r + 1], wsm[r + 1], wsl[r + 1]);
+                store_w_round(r, wn);
+                store_w_round(r + 1, wn);
                 if (!(abl & 4)) { load_w_round(r, wrs); load_w_round(r + 1, wrs); }
                 __builtin_amdgcn_sched_barrier(0);
             }
             static_assert(X3_XR % 2 == 0 && X3_WR % 2 == 1, "pairing of the staging rounds");
             if (!(abl & 4)) asm_wait14(pw[X3_WR - 1]);
-            x3_split4(pw[X3_WR - 1], wsh[X3_WR - 1], wsm[X3_WR - 1], wsl[X3_WR - 1]);
+            store_w_round(X3_WR - 1, wn);
             if (!(abl & 4)) load_w_round(X3_WR - 1, wrs);
             __builtin_amdgcn_sched_barrier(0);
             X3_LTICK(1);
-            if (more1) {
-                lds_barrier();                                                             // (A)
-                X3_LTICK(2);
-                store_w();
-                X3_LTICK(3);
-                lds_barrier();                                                             // (B)
-            }
+            lds_barrier();                                                                 // end of half-step `it`
+            X3_LTICK(2);
             n1 = n2; t1 = t2;
             n2 = succ(n2);
             if (it + 3 < items && n2.k != n1.k) { t2 = tile_of(n2.k); tile_offsets(t2); }
@@ -321,75 +327,90 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
         for (int q = 0; q < 4; ++q) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + j * 32 + 8 * q + 4 * hh);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { acc[0][4 * q + t] = bv[t]; acc[1][4 * q + t] = bv[t]; accx[0][4 * q + t] = 0.f; accx[1][4 * q + t] = 0.f; }
+            for (int t = 0; t < 4; ++t) {   // the accumulators are in scaled units: sum (sx x)(sw w) = sx sw * (true sum)
+                const float b = bv[t] * (sx * sw);
+                acc[0][4 * q + t] = b; acc[1][4 * q + t] = b; accx[0][4 * q + t] = 0.f; accx[1][4 * q + t] = 0.f;
+            }
         }
     };
-    const char* wl = w_lds + lane * 16;
-    // One half-step of a wave: 2 output rows x 32 pixels x 32 output channels, 9 taps x 16 input channels, 108 MFMAs.
-    // The LDS read path is the co-limiter of this kernel (8 waves x 81 KB per half-step is the CU's whole 128 B/clk for
-    // 5k cycles, measured with the MFMAs ablated), so fragments are reused in registers: the walk goes over the four INPUT
-    // rows the two output rows touch; an input row's fragment (ir, dx) serves output row 0 with tap dy = ir and output row 1
-    // with tap dy = ir - 1, and a tap's weight fragment is kept for the next input row.  63 ds_read_b128 instead of 81.
+    // One half-step of a wave: 2 output rows x 32 pixels x 32 output channels, 9 taps x 16 input channels, 54 MFMAs.
+    // The walk goes over the four INPUT rows the two output rows touch: an input row's fragment (ir, dx) serves output row 0
+    // with tap dy = ir and output row 1 with tap dy = ir - 1, and a tap's weight fragment is kept for the next input row
+    // (42 ds_read_b128 per half-step).
     // A finished tile's results wait in `pend` and are stored one float4 per lane at a time during the next half-step's
     // MFMA walk: eight waves storing their 8 KB at once is a 64-KB burst into a store path that takes ~10 B/clk per CU,
     // i.e. ~6k cycles with the matrix pipe idle.
+    // (buffer stores: a 32-bit lane offset per row against a wave-uniform descriptor of the output plane's batch slice; lanes
+    // outside the image carry an offset that fails the range check and are dropped by the hardware -- two registers instead
+    // of two 64-bit pointers that hipcc spills, and no trash page)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    float run_max = 0.f;      // max |stored in-image value| over everything this lane has produced in this launch
     f32x4 pend[8];
-    float* pend_dp[2];
-    auto store_pending = [&](int c) { *(x3_gstore_p)(pend_dp[c >> 2] + 8 * (c & 3)) = pend[c]; };
-    auto compute = [&](const char* xc, bool drip) {
-        bf16x8 xf[2][3], wf[2][3];   // [slot][term]: 0 = hi, 1 = mid, 2 = lo; weight slot = dy & 1
+    int pend_off[2];
+    unsigned int pend_lo = 0, pend_hi = 0;     // base address and byte size of the output plane's batch slice
+    int pend_nb = 0;
+    auto store_pending = [&](int c) {
+        // descriptor rebuilt from readfirstlane'd words at the use: carried across the loop as a descriptor, hipcc cannot
+        // prove it wave-uniform and wraps every store in a waterfall loop
+        const unsigned long long d = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(pend_hi) << 32) |
+                                     (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(pend_lo);   // (the builtin returns int: no sign extension)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(d), 0, __builtin_amdgcn_readfirstlane(pend_nb), 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pend[c]), rs, pend_off[c >> 2] + 32 * (c & 3), 0, 0);
+    };
+    auto compute = [&](const char* xc, int wpar, bool drip) {
+        f16x8 xf[3][2], wf[3][2];   // [slot][term]: 0 = hi, 1 = lo (scaled 2^11)
         // fragment base offsets rebuilt per half-step from the lane id (a few VALU): held across the loop they get spilled,
         // and a scratch reload in front of the MFMAs is a vector-memory round trip
         int abase[3];
+        // the lane id is recomputed (two mbcnt on a mask hipcc cannot see through) rather than kept in a register across the
+        // loop, where it gets spilled
+        unsigned int all = ~0u;
+        asm volatile("" : "+s"(all));
+        const int ln = (int)__builtin_amdgcn_mbcnt_hi(all, __builtin_amdgcn_mbcnt_lo(all, 0u));
+        const char* wl = w_lds + wpar * X3_WB + ln * 16;
         {
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const int hx = (ln & 31) + dx;
                 abase[dx] = (wv * 2) * X3_ROWB + hx * 32 + (((ln >> 5) ^ ((hx >> 3) & 1)) << 4);
             }
         }
-        auto load_w = [&](int tap, bf16x8 (&b)[3]) {
-#ifdef XSD_EXP_NOREAD    // timing experiment: MFMAs on whatever the registers hold
-            asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
-#else
+        auto load_w = [&](int tap, f16x8 (&b)[2]) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) b[t] = *reinterpret_cast<const bf16x8*>(wl + (tap * 3 + t) * 1024);
-#endif
+            for (int t = 0; t < 2; ++t) b[t] = *reinterpret_cast<const f16x8*>(wl + (tap * 2 + t) * 1024);
         };
-        auto load_x = [&](int ir, int dx, bf16x8 (&a)[3]) {
-#ifdef XSD_EXP_NOREAD
-            asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]));
-#else
+        auto load_x = [&](int ir, int dx, f16x8 (&a)[2]) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) a[t] = *reinterpret_cast<const bf16x8*>(xc + t * X3_XT + abase[dx] + ir * X3_ROWB);
-#endif
+            for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const f16x8*>(xc + t * X3_XT + abase[dx] + ir * X3_ROWB);
         };
-        auto mac = [&](int r, const bf16x8 (&w)[3], const bf16x8 (&x)[3]) {
-#ifdef XSD_EXP_NOMFMA    // timing experiment: fragment reads only
-            asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(x[0]), "v"(x[1]), "v"(x[2]));
-            return;
-#endif
-            accx[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[2], accx[r], 0, 0, 0);   // Wh * Xl
-            accx[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], x[0], accx[r], 0, 0, 0);   // Wl * Xh
-            accx[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[1], accx[r], 0, 0, 0);   // Wm * Xm
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[0], acc[r], 0, 0, 0);     // Wh * Xh
-            accx[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[1], accx[r], 0, 0, 0);   // Wh * Xm
-            accx[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[0], accx[r], 0, 0, 0);   // Wm * Xh
+        auto mac = [&](int r, const f16x8 (&w)[2], const f16x8 (&x)[2]) {
+            accx[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], x[1], accx[r], 0, 0, 0);   // Wh * Xl   } weighted 2^-11
+            accx[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1], x[0], accx[r], 0, 0, 0);   // Wl * Xh   } in the epilogue
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], x[0], acc[r], 0, 0, 0);     // Wh * Xh
         };
+        // Software pipeline over the 12 (column, input row) steps, TWO steps deep: the fragments of step s+2 are requested
+        // before the MFMAs of step s (scheduling barriers keep hipcc from sinking the reads next to their first use).  A
+        // step has only 3 or 6 MFMAs (96 / 192 cycles) here, one step of cover would expose the LDS latency every step.
+        // Three slots each: an input fragment lives 3 steps; a weight fragment (dy, dx), numbered n = 3 dx + dy in the order
+        // of first use, is requested two steps before its step 4 dx + dy and used there (row 0) and in the next step
+        // (row 1) -- any four consecutive n straddle a column change, i.e. an extra step, so n % 3 never collides.
         load_x(0, 0, xf[0]);
         load_w(0, wf[0]);
+        load_x(1, 0, xf[1]);
+        load_w(1 * 3 + 0, wf[1]);
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
             const int dx = s >> 2, ir = s & 3;
-            const int irn = (s + 1) & 3, dxn = (s + 1) >> 2;
-            if (s + 1 < 12) load_x(irn, dxn, xf[(s + 1) & 1]);
-            if (ir >= 1) mac(1, wf[(ir - 1) & 1], xf[s & 1]);      // output row 1, tap (dy = ir - 1, dx)
-            // two weight slots (dy & 1): the slot row 1 has just finished with takes the fragment the next step needs
-            if (s + 1 < 12 && irn <= 2) load_w(irn * 3 + dxn, wf[irn & 1]);
-            if (ir <= 2) mac(0, wf[ir & 1], xf[s & 1]);            // output row 0, tap (dy = ir, dx)
+            if (s + 2 < 12) {
+                const int dx2 = (s + 2) >> 2, ir2 = (s + 2) & 3;
+                load_x(ir2, dx2, xf[(s + 2) % 3]);
+                if (ir2 <= 2) load_w(ir2 * 3 + dx2, wf[(3 * dx2 + ir2) % 3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ir >= 1) mac(1, wf[(3 * dx + ir - 1) % 3], xf[s % 3]);      // output row 1, tap (dy = ir - 1, dx)
+            if (ir <= 2) mac(0, wf[(3 * dx + ir) % 3], xf[s % 3]);          // output row 0, tap (dy = ir, dx)
             if (drip && s >= 1 && s <= 8) store_pending(s - 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -403,10 +424,12 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
         const float s1 = (decltype(generic)::value && !o.e1) ? 0.f : o.s1, s2v = (decltype(generic)::value && !o.e2) ? 0.f : o.s2;
         const float s3 = (decltype(generic)::value && !o.e3) ? 0.f : o.s3, msl = (decltype(generic)::value && !o.mask) ? 1.f : o.mslope;
         const float sacc = (decltype(generic)::value && !o.accumulate) ? 0.f : 1.f;
+        const float a1e = o.a1 * inv_s;     // undoes the operand scales (a power of two: exact)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int y = T.y0 + wv * 2 + r;
             const bool valid = x < P.W && y < P.H;
+            const int doff = valid ? (y * o.rs + x * o.ps + 4 * h) * 4 : (int)0x80000000;
             float* dp = valid ? dst + (long long)y * o.rs + (long long)x * o.ps + 4 * h : trash;
             const long long os = sb + (long long)y * P.std_rs + x * 32 + 4 * h;
             auto opnd = [&](const float* plane) { return (valid && plane) ? plane + os : zero; };
@@ -425,7 +448,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
             for (int q = 0; q < 4; ++q) {
                 f32x4 v;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = (acc[r][4 * q + t] + accx[r][4 * q + t]) * o.a1;
+                for (int t = 0; t < 4; ++t) v[t] = (acc[r][4 * q + t] + accx[r][4 * q + t] * 0x1p-11f) * a1e;
                 if constexpr (decltype(has_acc)::value) v += sacc * va[q];
                 if constexpr (decltype(has_e1)::value) v += s1 * v1[q];
                 v *= o.a2;
@@ -438,8 +461,15 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
                     for (int t = 0; t < 4; ++t) v[t] = vm[q][t] > 0.f ? v[t] : v[t] * msl;
                 }
                 pend[4 * r + q] = v;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) run_max = __builtin_fmaxf(run_max, valid ? __builtin_fabsf(v[t]) : 0.f);   // select, no branch
             }
-            pend_dp[r] = dp;
+            pend_off[r] = doff;
+        }
+        {
+            const unsigned long long d = reinterpret_cast<unsigned long long>(dst);
+            pend_lo = (unsigned int)d; pend_hi = (unsigned int)(d >> 32);
+            pend_nb = (int)((unsigned int)P.H * (unsigned int)o.rs * 4u);
         }
     };
     auto epilogue = [&](int j, const TileXY& T) {
@@ -480,7 +510,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
         const bool more1 = (it + 1 < items);
         X3_TICK(1);
         if (cur.i == 0 && cur.s2 == 0) init_acc(cur.j);
-        compute(smem + (it & 1) * X3_XB, pending);
+        compute(smem + (it & 1) * X3_XB, it & 1, pending);
         pending = false;
         X3_TICK(2);
         if (cur.i == n_in - 1 && cur.s2 == 1) {
@@ -492,15 +522,34 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
             }
         }
         X3_TICK(3);
-        if (more1) {
-            lds_barrier();                                                                 // (A)
-            X3_TICK(4);
-            lds_barrier();                                                                 // (B)
-            X3_TICK(5);
-        }
+        lds_barrier();                                                                     // end of half-step `it`
+        X3_TICK(4);
         const Cur nx = succ(cur);
         if (nx.k != cur.k && more1) tcur = tile_of(nx.k);
         cur = nx;
+    }
+    // The planes' max |x| for the kernels that consume them (they scale their operands into the fp16 range with it): one
+    // value per launch -- for a launch with several output planes the maximum over all of them, a valid (if not the
+    // tightest) bound for each -- reduced over the wave by DPP (row shifts, then the two row broadcasts: lane 63 ends up with
+    // the maximum; 0 is the identity for non-negative values) and published with one atomic per wave and plane.  Done
+    // once at the end of the kernel: an atomic per tile would sit in front of the epilogue's vmcnt(0) for ~3k cycles.
+    {
+        auto dpp_max = [&](float x, auto ctrl, auto rowmask) {
+            const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(rowmask)::value, 0xf, true);
+            return __builtin_fmaxf(x, __builtin_bit_cast(float, t));
+        };
+        float m = run_max;
+        m = dpp_max(m, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});   // row_shr:1
+        m = dpp_max(m, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});   // row_shr:2
+        m = dpp_max(m, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});   // row_shr:4
+        m = dpp_max(m, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});   // row_shr:8
+        m = dpp_max(m, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 -> rows 1, 3
+        m = dpp_max(m, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast:31 -> rows 2, 3
+        if (lane == 63) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                if (j < n_out && P.out[j].amax) atomicMax(reinterpret_cast<unsigned int*>(P.out[j].amax), __float_as_uint(m));   // non-negative floats order as integers
+        }
     }
 #ifdef XSD_DIAG
     if (stamp && tid == 64 * X3_LWAVES) {
@@ -515,12 +564,12 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
 #endif
 }
 
-hipError_t launch_conv3x3_s3x(const ConvParams& p, hipStream_t stream)
+hipError_t launch_conv3x3_h2x(const ConvParams& p, hipStream_t stream)
 {
     static bool done = false;
     static int ncu = 256;
     if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_s3x_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2x_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
         if (e != hipSuccess) return e;
         hipDeviceProp_t prop;
@@ -533,7 +582,7 @@ hipError_t launch_conv3x3_s3x(const ConvParams& p, hipStream_t stream)
     const int ntiles = p.B * p.tilesX * tilesY;
     if (ntiles <= 0) return hipSuccess;
     const dim3 g(ntiles < ncu ? ntiles : ncu), b(X3_THREADS);
-    hipLaunchKernelGGL(conv3x3_s3x_kernel, g, b, X3_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(conv3x3_h2x_kernel, g, b, X3_LDS_BYTES, stream, p);
     return hipGetLastError();
 }
 

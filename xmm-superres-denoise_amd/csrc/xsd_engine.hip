@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <map>
+#include <tuple>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -86,6 +88,10 @@ struct xsd_engine {
     PackDesc* descs_dev = nullptr;
     int ndesc = 0;
     long long pk_floats = 0;
+    // math mode 4 (f16x3): max |x| slots; [0] packed forward panels, [1] packed input-gradient panels, [2..] planes of the plan
+    float* amax = nullptr;
+    int amax_used = 2;
+    static constexpr int AMAX_CAP = 8192;
     const float* params = nullptr; // borrowed (bias reads)
     bool packed = false;
     // workspace
@@ -172,6 +178,19 @@ static hipError_t prof_launch(xsd_engine* e, int klass, double flop, double byte
     return err;
 }
 
+// conv launch of the engine's math mode (mode 4 also needs the weight buffers' max |w| slot: forward or input-gradient panels)
+static hipError_t launch_conv_any(xsd_engine* eng, ConvParams& p, hipStream_t s)
+{
+    if (eng->math == 4) {
+        if (!p.amax_w) {
+            const float* lo = reinterpret_cast<const float*>(eng->pk_fwd_s);
+            p.amax_w = (p.wstep[0] >= lo && p.wstep[0] < lo + eng->pk_floats) ? eng->amax + 0 : eng->amax + 1;
+        }
+        return launch_conv3x3_h2x(p, s);
+    }
+    return eng->math == 3 ? launch_conv_bf16x6(eng->ablate, p, s) : eng->math == 2 ? launch_conv3x3_p16(p, s) : launch_conv3x3_mfma(p, eng->math, s);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Plan builder
 // ------------------------------------------------------------------------------------------------------------
@@ -182,8 +201,38 @@ struct Builder {
     uintptr_t base;      // 0 in the sizing pass
     size_t top = 0, peak = 0;
     std::vector<std::vector<size_t>> freelist; // per level
+    // math mode 4 (f16x3): which plane views have a slot holding their max |x| (set by the producing conv's epilogue or by
+    // a plane_amax launch in front of the first consumer); a view dies when its buffer is handed out again
+    typedef std::tuple<uintptr_t, int, int> ViewKey;
+    std::map<ViewKey, float*> amax_valid;
     Builder(xsd_engine* e_, int B_, int H_, int W_, bool train_, uintptr_t base_)
         : e(e_), B(B_), H(H_), W(W_), train(train_), base(base_), freelist(8) {}
+
+    float* new_slot()
+    {
+        if (e->amax_used >= xsd_engine::AMAX_CAP) return e->amax ? e->amax + xsd_engine::AMAX_CAP - 1 : nullptr;   // (never: ~10 slots per conv)
+        const int i = e->amax_used++;
+        return e->amax ? e->amax + i : nullptr;
+    }
+    void invalidate_range(uintptr_t lo, size_t bytes)
+    {
+        for (auto it = amax_valid.begin(); it != amax_valid.end();) {
+            const uintptr_t k = std::get<0>(it->first);
+            if (k >= lo && k < lo + bytes) it = amax_valid.erase(it); else ++it;
+        }
+    }
+    // slot of an input view; if nobody has reported it yet, `pre` gets the reduction launch
+    float* slot_of(const PlaneIn& v, int Hv, int Wv, std::vector<Launch>& pre)
+    {
+        const ViewKey key(reinterpret_cast<uintptr_t>(v.p), v.rs, v.ps);
+        auto it = amax_valid.find(key);
+        if (it != amax_valid.end()) return it->second;
+        float* slot = new_slot();
+        amax_valid[key] = slot;
+        const int Bv = B;
+        pre.push_back([v, Bv, Hv, Wv, slot](hipStream_t s) { return launch_plane_amax(v, Bv, Hv, Wv, slot, s); });
+        return slot;
+    }
 
     size_t plane_bytes(int level, int ch = 32) const
     {
@@ -194,6 +243,7 @@ struct Builder {
         size_t off;
         if (!freelist[level].empty()) { off = freelist[level].back(); freelist[level].pop_back(); }
         else { off = top; top += plane_bytes(level); if (top > peak) peak = top; }
+        if (e->math == 4) invalidate_range(base + off, plane_bytes(level));
         return reinterpret_cast<float*>(base + off);
     }
     float* alloc1(int level) // 1-channel image
@@ -278,12 +328,23 @@ struct Builder {
         const double px = (double)p.B * p.H * p.W;
         const double flop = 2.0 * 9 * 32 * 32 * p.n_in * p.n_out * px;
         const double bytes = 128.0 * (p.n_in + p.n_out) * px;
-        return [eng, p, bias_from_params, bias_off, flop, bytes](hipStream_t s) mutable {
+        std::vector<Launch> pre;     // math mode 4: reductions for input planes nobody has reported yet
+        if (e->math == 4) {
+            for (int i = 0; i < p.n_in; ++i) p.amax_in[i] = slot_of(p.in[i], p.H, p.W, pre);
+            for (int j = 0; j < p.n_out; ++j) {   // this launch reports its own outputs
+                OutDesc& o = p.out[j];
+                invalidate_range(reinterpret_cast<uintptr_t>(o.p), 1);
+                o.amax = new_slot();
+                amax_valid[ViewKey(reinterpret_cast<uintptr_t>(o.p), o.rs, o.ps)] = o.amax;
+            }
+        }
+        return [eng, p, pre, bias_from_params, bias_off, flop, bytes](hipStream_t s) mutable {
             if (bias_from_params) p.bias = eng->params + bias_off;
             p.dbg = eng->dbg;
             p.ablate = eng->ablate;
             p.zero = eng->zero_page;
-            return prof_launch(eng, 0, flop, bytes, s, [&]() { return eng->math == 3 ? launch_conv_bf16x6(eng->ablate, p, s) : eng->math == 2 ? launch_conv3x3_p16(p, s) : launch_conv3x3_mfma(p, eng->math, s); });
+            for (auto& f : pre) { hipError_t err = f(s); if (err != hipSuccess) return err; }
+            return prof_launch(eng, 0, flop, bytes, s, [&]() { return launch_conv_any(eng, p, s); });
         };
     }
     // wgrad + fixed-order reduce into the flat gradient vector
@@ -295,7 +356,7 @@ struct Builder {
         memset(&wp, 0, sizeof(wp));
         wp.B = B; wp.H = H << level; wp.W = W << level;
         wp.tilesX = (wp.W + TILE_W - 1) / TILE_W; wp.tilesY = (wp.H + TILE_H - 1) / TILE_H;
-        wp.n_in = (int)xs.size(); wp.n_g = (int)gs.size(); wp.nparts = e->math == 3 ? wgrad_bf16x6_parts(e->ablate, e->nparts) : e->nparts;
+        wp.n_in = (int)xs.size(); wp.n_g = (int)gs.size(); wp.nparts = e->math >= 3 ? wgrad_bf16x6_parts(e->ablate, e->nparts) : e->nparts;
         for (size_t i = 0; i < xs.size(); ++i) wp.x[i] = xs[i];
         for (size_t i = 0; i < gs.size(); ++i) wp.g[i] = gs[i];
         WgradReduceParams rp;
@@ -311,7 +372,7 @@ struct Builder {
             rp.partial = eng->wg_partial; rp.bias_partial = eng->wg_bias_partial;
             rp.dw = eng->b_grads + w_off; rp.db = eng->b_grads + b_off;
             wp.zero = eng->zero_page; wp.ablate = eng->ablate; wp.dbg = eng->dbg; rp.p16 = eng->math == 2;
-            hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return eng->math == 3 ? launch_wgrad_bf16x6(eng->ablate, wp, s) : eng->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, eng->math, s); });
+            hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return eng->math >= 3 ? launch_wgrad_bf16x6(eng->ablate, wp, s) : eng->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, eng->math, s); });
             if (err != hipSuccess) return err;
             return launch_wgrad_reduce(rp, s);
         });
@@ -561,6 +622,7 @@ static int ensure_plan(xsd_engine* e, int B, int H, int W, bool train)
     if (e->pB == B && e->pH == H && e->pW == W && e->ptrain == (int)train) return XSD_OK;
     e->pB = e->pH = e->pW = 0; e->ptrain = -1; e->fwd_saved = false;
     Builder sizing(e, B, H, W, train, 0);
+    e->amax_used = 2;
     sizing.build();
     const size_t need = sizing.peak + 256;
     if (need > e->ws_bytes) {
@@ -569,6 +631,7 @@ static int ensure_plan(xsd_engine* e, int B, int H, int W, bool train)
         if (err != hipSuccess) return fail(XSD_ERR_NOMEM, "workspace hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(err));
         e->ws_bytes = need;
     }
+    e->amax_used = 2;
     Builder real(e, B, H, W, train, reinterpret_cast<uintptr_t>(e->ws));
     real.build();
     e->pB = B; e->pH = H; e->pW = W; e->ptrain = (int)train;
@@ -603,7 +666,7 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     if (const char* m = getenv("XSD_ABLATE")) e->ablate = atoi(m);
     if (const char* m = getenv("XSD_CHUNK")) e->chunk = atoi(m);
 #endif
-    if (const char* m = getenv("XSD_MATH")) e->math = (strcmp(m, "bf16x6") == 0 || strcmp(m, "3") == 0) ? 3 : (strcmp(m, "bf16x3_p16") == 0 || strcmp(m, "2") == 0) ? 2 : (strcmp(m, "bf16x3") == 0 || strcmp(m, "1") == 0) ? 1 : 0;
+    if (const char* m = getenv("XSD_MATH")) e->math = (strcmp(m, "f16x3") == 0 || strcmp(m, "4") == 0) ? 4 : (strcmp(m, "bf16x6") == 0 || strcmp(m, "3") == 0) ? 3 : (strcmp(m, "bf16x3_p16") == 0 || strcmp(m, "2") == 0) ? 2 : (strcmp(m, "bf16x3") == 0 || strcmp(m, "1") == 0) ? 1 : 0;
     const int blocks = cfg->num_res_blocks, nup = cfg->kind == XSD_KIND_SR ? cfg->num_upsample : 0;
     long long off = 0, pk = 0, sb = 0;
     take_conv(off, 32, 1, e->first_w, e->first_b);
@@ -644,6 +707,8 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     CK(hipMalloc((void**)&e->pk_bwd, sizeof(float) * pk));
     CK(hipMalloc((void**)&e->pk_fwd_s, sizeof(float) * pk));
     CK(hipMalloc((void**)&e->pk_bwd_s, sizeof(float) * pk));
+    CK(hipMalloc((void**)&e->amax, sizeof(float) * xsd_engine::AMAX_CAP));
+    CK(hipMemset(e->amax, 0, sizeof(float) * xsd_engine::AMAX_CAP));
     CK(hipMalloc((void**)&e->zero_page, 512));   // [0,256): zeros (padding source); [256,512): trash (stores of lanes outside the image)
     CK(hipMemset(e->zero_page, 0, 512));
     CK(hipMalloc((void**)&e->pk_edge, sizeof(float) * 4 * 288));
@@ -664,7 +729,7 @@ void xsd_destroy(xsd_engine* e)
     if (!e) return;
     hipDeviceSynchronize();
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
-    hipFree(e->pk_fwd); hipFree(e->pk_bwd); hipFree(e->pk_fwd_s); hipFree(e->pk_bwd_s); hipFree(e->zero_page); hipFree(e->pk_edge); hipFree(e->pk_sbias); hipFree(e->descs_dev);
+    hipFree(e->pk_fwd); hipFree(e->pk_bwd); hipFree(e->pk_fwd_s); hipFree(e->pk_bwd_s); hipFree(e->zero_page); hipFree(e->amax); hipFree(e->pk_edge); hipFree(e->pk_sbias); hipFree(e->descs_dev);
     hipFree(e->wg_partial); hipFree(e->wg_bias_partial); hipFree(e->edge_partial); hipFree(e->loss_partial);
     hipFree(e->ws);
     delete e;
@@ -674,7 +739,7 @@ int64_t xsd_param_count(const xsd_engine* e) { return e ? e->nparams : 0; }
 
 int xsd_set_math(xsd_engine* e, int mode)
 {
-    if (!e || mode < 0 || mode > 3) return fail(XSD_ERR_ARG, "math mode must be 0 (fp32), 1 (bf16x3), 2 (bf16x3 over P16 planes) or 3 (bf16x6, fp32-class)");
+    if (!e || mode < 0 || mode > 4) return fail(XSD_ERR_ARG, "math mode must be 0 (fp32), 1 (bf16x3), 2 (bf16x3 over P16 planes), 3 (bf16x6, fp32-class) or 4 (f16x3, fp32-class)");
     if (mode != e->math) { e->math = mode; e->packed = false; e->pB = 0; e->ptrain = -1; e->fwd_saved = false; }
     return XSD_OK;
 }
@@ -685,8 +750,14 @@ int xsd_pack_weights(xsd_engine* e, const float* dev_params, void* stream)
     if (!e || !dev_params) return fail(XSD_ERR_ARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
     e->params = dev_params;
-    if (e->math == 3)
+    if (e->math >= 3) {
         HIPCHK(launch_pack_weights_s3(dev_params, e->descs_dev, e->ndesc, reinterpret_cast<float*>(e->pk_fwd_s), reinterpret_cast<float*>(e->pk_bwd_s), s));
+        if (e->math == 4) {   // max |w| of the forward and of the input-gradient panels (one power-of-two scale each)
+            HIPCHK(hipMemsetAsync(e->amax, 0, 2 * sizeof(float), s));
+            HIPCHK(launch_buffer_amax(reinterpret_cast<const float*>(e->pk_fwd_s), e->pk_floats, e->amax + 0, s));
+            HIPCHK(launch_buffer_amax(reinterpret_cast<const float*>(e->pk_bwd_s), e->pk_floats, e->amax + 1, s));
+        }
+    }
     else if (e->math == 2)
         HIPCHK(launch_pack_weights_p16(dev_params, e->descs_dev, e->ndesc, e->pk_fwd_s, e->pk_bwd_s, s));
     else if (e->math == 1)
@@ -712,6 +783,7 @@ int xsd_forward(xsd_engine* e, const float* dev_x, float* dev_y, int B, int H, i
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     e->b_x = dev_x; e->b_y = dev_y;
+    if (e->math == 4 && e->amax_used > 2) HIPCHK(hipMemsetAsync(e->amax + 2, 0, sizeof(float) * (e->amax_used - 2), s));   // every plane slot of the plan (forward and backward)
     for (auto& op : e->fwd_ops) HIPCHK(op(s));
     e->fwd_saved = save_for_backward != 0;
     return XSD_OK;
@@ -916,7 +988,7 @@ static int pack_single(const float* dev_w, int cout, int cin, float** fwd, float
     HIPCHK(hipMalloc((void**)bwd, sizeof(float) * n));
     HIPCHK(hipMalloc((void**)&dd, sizeof(PackDesc)));
     HIPCHK(hipMemcpy(dd, &d, sizeof(d), hipMemcpyHostToDevice));
-    if (math == 3) HIPCHK(launch_pack_weights_s3(dev_w, dd, 1, *fwd, *bwd, s));
+    if (math >= 3) HIPCHK(launch_pack_weights_s3(dev_w, dd, 1, *fwd, *bwd, s));
     else if (math == 2) HIPCHK(launch_pack_weights_p16(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
     else if (math == 1) HIPCHK(launch_pack_weights_split(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
     else HIPCHK(launch_pack_weights(dev_w, dd, 1, *fwd, *bwd, s));
@@ -936,6 +1008,20 @@ static hipError_t run_conv(xsd_engine* e, ConvParams& p, hipStream_t s)
 {
     p.zero = e->zero_page;
     for (int i = 0; i < (p.n_out > 1 ? p.n_out : p.n_in); ++i) p.wstep[i] = p.wpanel + (long long)i * PANEL_FLOATS;
+    if (e->math == 4) {   // test hook: nobody has reported the operands' max |x| -> reduce them here (slots at the end of the array)
+        float* t = e->amax + xsd_engine::AMAX_CAP - 8;
+        hipError_t err = hipMemsetAsync(t, 0, 8 * sizeof(float), s);
+        if (err != hipSuccess) return err;
+        for (int i = 0; i < p.n_in; ++i) {
+            err = launch_plane_amax(p.in[i], p.B, p.H, p.W, t + i, s);
+            if (err != hipSuccess) return err;
+            p.amax_in[i] = t + i;
+        }
+        err = launch_buffer_amax(p.wpanel, (long long)p.n_in * p.n_out * PANEL_FLOATS, t + 5, s);
+        if (err != hipSuccess) return err;
+        p.amax_w = t + 5;
+        return launch_conv3x3_h2x(p, s);
+    }
     if (e->math == 3) return launch_conv_bf16x6(e->ablate, p, s);
     if (e->math == 2) return launch_conv3x3_p16(p, s);
     return launch_conv3x3_mfma(p, e->math, s);
@@ -1007,11 +1093,11 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
     hipError_t err = run_conv(e, p, s);
     if (err == hipSuccess) {
         WgradParams wp; memset(&wp, 0, sizeof(wp));
-        wp.B = B; wp.H = H; wp.W = W; wp.tilesX = p.tilesX; wp.tilesY = p.tilesY; wp.n_in = n_in; wp.n_g = 1; wp.nparts = e->math == 3 ? wgrad_bf16x6_parts(e->ablate, e->nparts) : e->nparts;
+        wp.B = B; wp.H = H; wp.W = W; wp.tilesX = p.tilesX; wp.tilesY = p.tilesY; wp.n_in = n_in; wp.n_g = 1; wp.nparts = e->math >= 3 ? wgrad_bf16x6_parts(e->ablate, e->nparts) : e->nparts;
         for (int i = 0; i < n_in; ++i) wp.x[i] = b.std_in(ins[i], 0);
         wp.g[0] = b.std_in(g, 0);
         wp.partial = e->wg_partial; wp.bias_partial = e->wg_bias_partial; wp.zero = e->zero_page;
-        err = e->math == 3 ? launch_wgrad_bf16x6(e->ablate, wp, s) : e->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, e->math, s);
+        err = e->math >= 3 ? launch_wgrad_bf16x6(e->ablate, wp, s) : e->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, e->math, s);
         if (err == hipSuccess) {
             WgradReduceParams rp; memset(&rp, 0, sizeof(rp));
             rp.partial = e->wg_partial; rp.bias_partial = e->wg_bias_partial; rp.nparts = wp.nparts; rp.n_in = n_in; rp.n_g = 1;

@@ -20,6 +20,8 @@ constexpr int W_LDS_BYTES = PANEL_FLOATS * 4;   // 36,864
 constexpr int CONV_LDS_BYTES = IN_LDS_BYTES + W_LDS_BYTES; // 80,384 -> 2 workgroups per CU (160 KiB LDS)
 // math mode 3 (bf16x6, conv3x3_s3.hip): a weight half-panel in LDS, split into three bf16 terms: [tap][hi|mid|lo][64 lanes][8 bf16]
 constexpr int S3_WH_BYTES = 9 * 3 * 1024;           // 27,648
+// math mode 4 (f16x3, conv3x3_h2x.hip): two fp16 terms: [tap][hi|lo][64 lanes][8 f16]
+constexpr int H2_WH_BYTES = 9 * 2 * 1024;           // 18,432
 
 // input plane reference with general strides (pixel-shuffled reads use rs = 2*Whr*32, ps = 64)
 struct PlaneIn {
@@ -48,6 +50,8 @@ struct OutDesc {
     // the input-gradient conv masked by that activation reads them (bits_in) instead of the 128 B-per-pixel plane.
     unsigned short* bits_out;
     const unsigned short* bits_in;
+    // math mode 4 (f16x3): slot that receives max |stored value| of this plane (atomic max of the float bits), or null
+    float* amax;
 };
 
 struct ConvParams {
@@ -69,6 +73,10 @@ struct ConvParams {
     int pad_;
     const void* zero;    // >= 64 B of zeros in HBM (math mode 2: DMA source for zero padding)
     unsigned long long* dbg; // diagnostic phase stamps (null in production): [grid][8] accumulated shader cycles
+    // math mode 4 (f16x3): max |x| of each input plane and of the weight panels of this launch (device slots written by
+    // the producers, read at kernel start); the kernel scales both operands by powers of two into the fp16 range
+    const float* amax_in[5];
+    const float* amax_w;
     OutDesc out[5];
 };
 
@@ -86,6 +94,8 @@ struct WgradParams {
     int ablate;          // diagnostic (env XSD_ABLATE): 4096 = request the G tile only for the first tile of a workgroup
     int pad_;
     unsigned long long* dbg; // diagnostic phase stamps (null in production): slots [8..15] of the engine's stamp buffer
+    const float* amax_x[5]; // math mode 4 (f16x3): max |x| slots of the X and G planes
+    const float* amax_g[4];
 };
 
 struct WgradReduceParams {

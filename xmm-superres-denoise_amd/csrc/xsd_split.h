@@ -50,4 +50,46 @@ __device__ __forceinline__ void split3_f32x4(const split_f32x4& a, split_u32x2& 
     lo[0] = l0; lo[1] = l1;
 }
 
+// ---- math mode 4 ("f16x3"): two-term fp16 split of a SCALED fp32 value --------------------------------------------------
+// xs = x * s (s a power of two chosen from the tensor's max |x| so that |xs| < 2^14: scale_for_amax below),
+// h = fp16(xs) (RNE, 11 significant bits), l = fp16((xs - h) * 2^11) (the next 11 bits, kept at h's magnitude so that it never
+// falls into the fp16 subnormals before h does).  xs = h + l * 2^-11 up to 2^-22 |xs| (half an ulp of l), i.e. 22-23 of
+// fp32's 24 significant bits; the product of two such operands is taken as h*h + (h*l + l*h) * 2^-11 (three fp16 MFMAs,
+// the two cross products into a second accumulator).  Network-level error against float64: tools/sim_split3.py and
+// tests/test_hip_precision.py.  20 VALU per float4.
+typedef _Float16 split_f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2_f16_pair(float x0, float x1, float s, unsigned int& h, unsigned int& l)
+{
+    const float a0 = x0 * s, a1 = x1 * s;
+    split_f32x2 a; a[0] = a0; a[1] = a1;
+    const split_f16x2 hh = __builtin_convertvector(a, split_f16x2);          // v_cvt_pk_f16_f32 (RNE)
+    h = __builtin_bit_cast(unsigned int, hh);
+    const float r0 = split_sub(a0, (float)hh[0]), r1 = split_sub(a1, (float)hh[1]);   // exact
+    split_f32x2 r; r[0] = r0 * 2048.f; r[1] = r1 * 2048.f;
+    l = __builtin_bit_cast(unsigned int, __builtin_convertvector(r, split_f16x2));
+}
+
+__device__ __forceinline__ void split2_f16x4(const split_f32x4& a, float s, split_u32x2& hi, split_u32x2& lo)
+{
+    unsigned int h0, l0, h1, l1;
+    split2_f16_pair(a[0], a[1], s, h0, l0);
+    split2_f16_pair(a[2], a[3], s, h1, l1);
+    hi[0] = h0; hi[1] = h1;
+    lo[0] = l0; lo[1] = l1;
+}
+
+// power of two s with amax * s in [2^13, 2^14) (1 for amax = 0, subnormal, inf or NaN); exponent clamped to +-60 so that
+// products of two scales and their reciprocals stay finite.  `inv` receives 1 / s.
+__device__ __forceinline__ float scale_for_amax(float amax, float& inv)
+{
+    const unsigned int u = __builtin_bit_cast(unsigned int, amax);
+    const int ex = (int)((u >> 23) & 0xff);
+    int k = 140 - ex;                       // amax in [2^(ex-127), 2^(ex-126))  ->  s = 2^(14 - (ex - 126))
+    if (ex == 0 || ex == 255) k = 0;
+    k = k > 60 ? 60 : (k < -60 ? -60 : k);
+    inv = __builtin_bit_cast(float, (unsigned int)(127 - k) << 23);
+    return __builtin_bit_cast(float, (unsigned int)(127 + k) << 23);
+}
+
 } // namespace xsd

@@ -56,7 +56,7 @@ class Engine:
         except Exception:
             pass
 
-    MATH = {"fp32": 0, "bf16x3": 1, "bf16x3_p16": 2, "bf16x6": 3}
+    MATH = {"fp32": 0, "bf16x3": 1, "bf16x3_p16": 2, "bf16x6": 3, "f16x3": 4}
 
     def set_math(self, mode: str):
         """'fp32' (exact fp32 MFMA), 'bf16x6' (fp32-class: exact 3-term bf16 split, 6 products, single-rounding MFMA

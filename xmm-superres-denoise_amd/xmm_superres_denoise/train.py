@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--batch-size", type=int, default=4)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--checkpoint", default=None)
-    ap.add_argument("--math", default=None, choices=[None, "fp32", "bf16x6", "bf16x3", "bf16x3_p16"])
+    ap.add_argument("--math", default=None, choices=[None, "fp32", "bf16x6", "f16x3", "bf16x3", "bf16x3_p16"])
     ap.add_argument("--loss", default="l1", choices=["l1", "paper"], help="paper = 0.5 psnr + 0.5 ms_ssim (loss_functions.toml)")
     ap.add_argument("--scaling", default="linear", choices=["linear", "sqrt", "asinh", "log"])
     ap.add_argument("--val-batches", type=int, default=0, help="validation batches after training (loss + metric set)")
