@@ -17,7 +17,7 @@ from util_hip import G, build_module
 
 pytestmark = pytest.mark.gpu
 
-HEADLINE = "bf16x6"
+HEADLINE = "f16x3"
 
 
 def _tiles(shape, seed):

@@ -47,7 +47,7 @@ def _launch(out_dir, world, backend, steps, math, kind="dn"):
     return [np.load(os.path.join(out_dir, f"rank{r}.npz")) for r in range(world)]
 
 
-@pytest.mark.parametrize("math,kind", [("bf16x6", "dn"), ("fp32", "dn"), ("bf16x6", "sr")])
+@pytest.mark.parametrize("math,kind", [("f16x3", "dn"), ("bf16x6", "dn"), ("fp32", "dn"), ("f16x3", "sr")])
 def test_two_ranks_on_hip_engine_match_single_process_full_batch(tmp_path, math, kind):
     """kind "sr": the per-GPU share of BASELINE configs[3] (SR train, data parallel), two ranks"""
     import dp_worker as W

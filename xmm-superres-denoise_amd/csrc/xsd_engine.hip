@@ -82,7 +82,7 @@ struct xsd_engine {
     unsigned short* pk_bwd_s = nullptr;
     int chunk = 0;             // diagnostic library only (env XSD_CHUNK): images per dense-block sweep (0 = whole batch)
     int ablate = 0;            // diagnostic library only (env XSD_ABLATE): ablation knobs of the kernels
-    int math = 3;              // include/xsd.h: xsd_set_math (default: bf16x6, the fp32-class split mode)
+    int math = 4;              // include/xsd.h: xsd_set_math (default: f16x3, the faster of the two fp32-class split modes)
     float* pk_edge = nullptr; // first_fwd, first_bwd, last_fwd, last_bwd (288 each)
     float* pk_sbias = nullptr;
     PackDesc* descs_dev = nullptr;

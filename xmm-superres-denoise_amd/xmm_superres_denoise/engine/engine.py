@@ -59,8 +59,9 @@ class Engine:
     MATH = {"fp32": 0, "bf16x3": 1, "bf16x3_p16": 2, "bf16x6": 3, "f16x3": 4}
 
     def set_math(self, mode: str):
-        """'fp32' (exact fp32 MFMA), 'bf16x6' (fp32-class: exact 3-term bf16 split, 6 products, single-rounding MFMA
-        accumulation, fp32 planes), 'bf16x3' (2-term split, 16-bit significands, fp32 planes) or 'bf16x3_p16' (2-term
+        """'fp32' (exact fp32 MFMA), 'f16x3' (default; fp32-class: 2-term fp16 split of power-of-two-scaled operands, 3
+        products), 'bf16x6' (fp32-class: exact 3-term bf16 split, 6 products, single-rounding MFMA accumulation, fp32
+        planes), 'bf16x3' (2-term split, 16-bit significands, fp32 planes) or 'bf16x3_p16' (2-term
         split over pre-split P16 planes, LDS-DMA staging); include/xsd.h: xsd_set_math."""
         check(self.L.xsd_set_math(self.h, self.MATH[mode]))
 

@@ -147,7 +147,7 @@ class _GeneratorRRDB(nn.Module):
         self._engine_dev = None
         self._flat = None
         self._plist = None
-        self._math = None  # None: engine default (env XSD_MATH, else bf16x6)
+        self._math = None  # None: engine default (env XSD_MATH, else f16x3)
 
     # ---- flat parameter buffer ---------------------------------------------------------------------------------
     def _num_upsample(self):
@@ -183,7 +183,7 @@ class _GeneratorRRDB(nn.Module):
         return self.flatten_parameters()
 
     def set_math(self, mode: str):
-        """Math mode of the conv kernels (Engine.set_math): 'fp32', 'bf16x6' (fp32-class split), 'bf16x3', 'bf16x3_p16'."""
+        """Math mode of the conv kernels (Engine.set_math): 'fp32', 'f16x3' and 'bf16x6' (fp32-class splits), 'bf16x3', 'bf16x3_p16'."""
         if mode not in Engine.MATH:
             raise ValueError(mode)
         self._math = mode
