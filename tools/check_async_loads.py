@@ -1,5 +1,5 @@
 """ISA check for the hand-counted prefetch of the staging waves of the role-split kernels (csrc/conv3x3_s3x.hip,
-csrc/conv3x3_h2x.hip, csrc/wgrad_s3x.hip).
+csrc/conv3x3_h2x.hip, csrc/wgrad_s3x.hip, csrc/wgrad_h2x.hip).
 
 The staging loop issues its global loads and their `s_waitcnt vmcnt(14)` from inline asm, so hipcc does not know that a
 load's destination registers are written asynchronously.  That is only correct if, in the generated code,
@@ -18,7 +18,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "xmm-superres-denoise_amd", "csrc")
-KERNELS = (("conv3x3_s3x.hip", 15), ("conv3x3_h2x.hip", 15), ("wgrad_s3x.hip", 11))     # source, counted loads per pass of the staging loop
+KERNELS = (("conv3x3_s3x.hip", 15), ("conv3x3_h2x.hip", 15), ("wgrad_s3x.hip", 11), ("wgrad_h2x.hip", 11))     # source, counted loads per pass of the staging loop
 
 
 def regs_of(tok):

@@ -1,0 +1,371 @@
+// wgrad_h2x.hip -- math mode 4 ("f16x3"): weight gradient of the 3x3 convs over fp32 planes with the two-term fp16 arithmetic
+// of conv3x3_h2x.hip; role-split workgroup as in wgrad_s3x.hip (4 staging + 4 MFMA waves, one workgroup per CU, 4 x 32-pixel
+// tiles, two LDS buffers, one barrier per tile; read that file for the staging scheme).  Replaces autograd's conv
+// weight-gradient for the reference's nn.Conv2d(32k -> 32n, 3,1,1) layers (rrdb_blocks.py:27-31; generator_rrdb.py:38-44,95,101):
+//     dW[co][ci][tap] = sum_{b,y,x} G[b,y,x,co] * X[b,y+dy-1,x+dx-1,ci],   db[co] = sum G[..,co]
+// Arithmetic: X and G are scaled by powers of two from their max |x| slots and split into h + l * 2^-11 (xsd_split.h); the
+// product is Xh*Gh + (Xh*Gl + Xl*Gh) * 2^-11: three v_mfma_f32_32x32x16_f16 per (16 pixels, tap) instead of six bf16 ones.
+// The three products carry different weights, so they need their own accumulators: 27 32x32 accumulators (9 taps x {hh, hl, lh})
+// do not fit one wave.  The 27 single-MFMA "units" are dealt 7/7/7/6 to the four MFMA waves; each wave walks ALL four rows of
+// the tile for its units (every wave reads a different subset of the fragments: the LDS read volume stays what it was), and the
+// weighted sum hh + 2^-11 (hl + lh), un-scaled exactly, is formed in the final fixed-order reduction.
+// LDS: four images [pixel][32 x f16] per buffer (X_h, X_l over the 6 x 34 halo, G_h, G_l): 42,496 B, two buffers.
+#include <type_traits>
+#include "xsd_kernels.h"
+#include "xsd_split.h"
+
+namespace xsd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int V3_TH = 4;                                              // tile rows = MFMA waves
+constexpr int V3_LT = 256;                                            // staging threads (waves 0..3)
+constexpr int V3_THREADS = V3_LT + 64 * V3_TH;                        // 512
+constexpr int V3_HPX = (V3_TH + 2) * HALO_W;                          // 204 halo pixels
+constexpr int V3_X_SLOTS = V3_HPX * 8;                                // 1632 (pixel, channel quad) slots
+constexpr int V3_X_ROUNDS = (V3_X_SLOTS + V3_LT - 1) / V3_LT;         // 7
+constexpr int V3_G_SLOTS = V3_TH * TILE_W * 8;                        // 1024
+constexpr int V3_G_ROUNDS = V3_G_SLOTS / V3_LT;                       // 4
+constexpr int V3_NL = V3_X_ROUNDS + V3_G_ROUNDS;                      // 11 loads per tile and staging thread
+constexpr int V3_XT = V3_HPX * 64;                                    // 13,056 B per X term image
+constexpr int V3_GT = V3_TH * TILE_W * 64;                            // 8,192 B per G term image
+constexpr int V3_G_OFF = 2 * V3_XT;                                   // 26,112
+constexpr int V3_BUF = V3_G_OFF + 2 * V3_GT;                          // 42,496 B per buffer
+constexpr int V3_SINK = 2 * V3_BUF;                                   // writes of exhausted slots land behind the buffers
+constexpr int V3_RED = 27 * 4096;                                     // final reduction: one 4 KiB slab per accumulator
+constexpr int V3_LDS_BYTES = (V3_SINK + V3_XT + 2048) > V3_RED ? (V3_SINK + V3_XT + 2048) : V3_RED;   // 110,592
+static_assert(V3_LDS_BYTES <= 160 * 1024, "LDS");
+
+
+// 8 consecutive pixels (k = 8h + 0..7) of this lane's channel from a [pixel][32 x bf16] image
+__device__ __forceinline__ f16x8 v3_tr_frag(const char* lds_lane_base, int byte_off)
+{
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds_lane_base + byte_off));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds_lane_base + byte_off + 4 * 64));
+    s16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return __builtin_bit_cast(f16x8, r);
+}
+
+__global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wid < 4;       // wave-uniform role
+    const int h = lane >> 5;
+    const int l31 = lane & 31;
+
+    // 1-D grid decode as in wgrad_s3.hip: the n_in workgroups that read the SAME G tiles have linear ids 8 apart -> one XCD
+    const int lin = blockIdx.x;
+    const int xcd = lin & 7, qq = lin >> 3;
+    const int j = qq % P.n_in;                        // input plane
+    const int rest = qq / P.n_in;
+    const int parts8 = P.nparts >> 3;
+    const int part = (rest % parts8) * 8 + xcd;
+    const int n = rest / parts8;                      // G chunk
+    const int tilesY = (P.H + V3_TH - 1) / V3_TH;
+    const int ntiles = P.B * tilesY * P.tilesX;
+    const int my_tiles = part < ntiles ? (ntiles - part + P.nparts - 1) / P.nparts : 0;
+
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+#ifdef XSD_DIAG   // phase stamps (diagnostic library only; tools/stamps_train.py): slot 8 staging rounds, 9 MFMA walk, 10 MFMA
+                  // wave at the barrier, 11 staging wave at the barrier, 13 tiles
+    unsigned long long st[2] = {0, 0};
+    unsigned long long t0 = __builtin_readcyclecounter();
+    const bool stamp = P.dbg != nullptr;
+#define V3_TICK(i) do { if (stamp) { const unsigned long long t_ = __builtin_readcyclecounter(); st[i] += t_ - t0; t0 = t_; } } while (0)
+#else
+#define V3_TICK(i) do { } while (0)
+#endif
+    // operand scales (powers of two) from the planes' max |x| slots; every wave computes the same values (scalar loads)
+    float sx, sg, inv_sx, inv_sg;
+    {
+        float ax = 1.f, ag = 1.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) if (i == j && P.amax_x[i]) ax = *P.amax_x[i];     // static indices into the kernel arguments
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i == n && P.amax_g[i]) ag = *P.amax_g[i];
+        sx = scale_for_amax(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ax))), inv_sx);
+        sg = scale_for_amax(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ag))), inv_sg);
+    }
+    const float inv_s = inv_sx * inv_sg;
+
+    constexpr int NU = 7;              // accumulators ("units") per MFMA wave: 27 = 7 + 7 + 7 + 6
+    f32x16 acc[NU];
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f}; // staging thread: its 4 channels (lt & 7) of the G tiles it stages
+
+    if (loader) {
+        // ============================ staging waves ============================
+        const int lt = tid;
+        const PlaneIn xp = P.x[j];
+        const PlaneIn gp = P.g[n];
+        constexpr int OOR = (int)0x80000000;          // lane offset that fails every range check -> the load returns 0
+        // per-slot constants: X round r -> halo pixel (hy, hx), channel quad c; byte offset relative to the tile origin
+        int xrel[V3_X_ROUNDS], xhx[V3_X_ROUNDS], grel[V3_G_ROUNDS], ggx[V3_G_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < V3_X_ROUNDS; ++r) {
+            const int slot = r * V3_LT + lt;
+            const int p = slot >> 3, c = slot & 7;
+            const int hy = p / HALO_W, hx = p - hy * HALO_W;
+            xrel[r] = slot < V3_X_SLOTS ? (hy * xp.rs + hx * xp.ps + c * 4) * 4 : OOR;
+            xhx[r] = slot < V3_X_SLOTS ? hx : 0x40000000;
+        }
+#pragma unroll
+        for (int r = 0; r < V3_G_ROUNDS; ++r) {
+            const int slot = r * V3_LT + lt;
+            const int p = slot >> 3, c = slot & 7;
+            grel[r] = ((p >> 5) * gp.rs + (p & 31) * gp.ps + c * 4) * 4;
+            ggx[r] = p & 31;
+        }
+        const int lds0 = lt * 8;
+        const bool live6 = 6 * V3_LT + lt < V3_X_SLOTS;          // last X round: 96 live threads, the others write a sink
+        static_assert(V3_X_ROUNDS == 7, "sink round");
+
+        f32x4 px[V3_X_ROUNDS] = {};
+        f32x4 pg[V3_G_ROUNDS] = {};
+        auto make_rsrc = [&](unsigned long long base, unsigned int bytes) {
+            i32x4 d;
+            d[0] = (int)(unsigned int)base; d[1] = (int)(unsigned int)((base >> 32) & 0xffffu);   // stride 0: raw buffer
+            d[2] = (int)bytes; d[3] = 0x00020000;
+            return d;
+        };
+        const unsigned int x_bytes = (unsigned int)P.H * (unsigned int)xp.rs * 4u;
+        const unsigned int g_bytes = (unsigned int)P.H * (unsigned int)gp.rs * 4u;
+        auto asm_load4 = [&](f32x4& dst, int off, const i32x4& rs) {
+            asm volatile("buffer_load_dwordx4 %[d], %[o], %[r], 0 offen" : [d] "+v"(dst) : [o] "v"(off), [r] "s"(rs) : "memory");
+        };
+        auto asm_wait = [&](f32x4& v) { asm volatile("s_waitcnt vmcnt(10)" : "+v"(v) :: "memory"); };
+        static_assert(V3_NL == 11, "the counted wait is vmcnt(V3_NL - 1)");
+
+        struct TileAt { i32x4 xrs, grs; int xorg, gorg, x0; };
+        auto tile_at = [&](int k) {        // descriptors and origin offsets of this workgroup's k-th tile (empty past the end)
+            const bool live = k < my_tiles;
+            const int t = part + k * P.nparts;
+            const int tx = t % P.tilesX;
+            const int t2 = t / P.tilesX;
+            const int ty = t2 % tilesY;
+            const int b = live ? t2 / tilesY : 0;
+            TileAt a;
+            a.x0 = tx * TILE_W;
+            const int y0 = ty * V3_TH;
+            a.xrs = make_rsrc(reinterpret_cast<unsigned long long>(xp.p + (long long)b * xp.bs), live ? x_bytes : 0u);
+            a.grs = make_rsrc(reinterpret_cast<unsigned long long>(gp.p + (long long)b * gp.bs), live ? g_bytes : 0u);
+            a.xorg = ((y0 - 1) * xp.rs + (a.x0 - 1) * xp.ps) * 4;    // rows above / below the image fall outside [0, bytes): zeros
+            a.gorg = (y0 * gp.rs + a.x0 * gp.ps) * 4;
+            return a;
+        };
+        // columns left / right of the image would alias the neighbouring row: those lanes get the failing offset
+        auto x_off = [&](int r, const TileAt& a) { return ((unsigned)(a.x0 - 1 + xhx[r]) < (unsigned)P.W) ? a.xorg + xrel[r] : OOR; };
+        auto g_off = [&](int r, const TileAt& a) { return (a.x0 + ggx[r] < P.W) ? a.gorg + grel[r] : OOR; };
+#ifdef XSD_DIAG
+        const int abl = P.ablate;     // 1: no split, 2: no LDS writes (results are garbage: timing experiments only)
+#else
+        constexpr int abl = 0;
+#endif
+        auto store_x = [&](int r, int buf) {
+            u32x2 hi, lo;
+            if (abl & 1) { hi[0] = __float_as_uint(px[r][0]); hi[1] = __float_as_uint(px[r][1]); lo[0] = __float_as_uint(px[r][2]); lo[1] = __float_as_uint(px[r][3]); }
+            else split2_f16x4(px[r], sx, hi, lo);
+            char* d = smem + ((r == 6 && !live6) ? V3_SINK + (lt & 63) * 8 : buf + lds0 + r * (V3_LT * 8));
+            if (abl & 2) { asm volatile("" :: "v"(hi), "v"(lo), "v"(d)); return; }   // diag: no LDS writes
+            *reinterpret_cast<u32x2*>(d) = hi;
+            *reinterpret_cast<u32x2*>(d + V3_XT) = lo;
+        };
+        auto store_g = [&](int r, int buf) {
+            u32x2 hi, lo;
+            if (abl & 1) { hi[0] = __float_as_uint(pg[r][0]); hi[1] = __float_as_uint(pg[r][1]); lo[0] = __float_as_uint(pg[r][2]); lo[1] = __float_as_uint(pg[r][3]); }
+            else split2_f16x4(pg[r], sg, hi, lo);
+            char* d = smem + buf + V3_G_OFF + lds0 + r * (V3_LT * 8);
+            if (abl & 2) { asm volatile("" :: "v"(hi), "v"(lo), "v"(d)); bsum += pg[r]; return; }
+            *reinterpret_cast<u32x2*>(d) = hi;
+            *reinterpret_cast<u32x2*>(d + V3_GT) = lo;
+            bsum += pg[r];
+        };
+
+        // prologue: tile 0 into LDS buffer 0, tile 1 into the staging registers
+        {
+            const TileAt a = tile_at(0);
+#pragma unroll
+            for (int r = 0; r < V3_X_ROUNDS; ++r) asm_load4(px[r], x_off(r, a), a.xrs);
+#pragma unroll
+            for (int r = 0; r < V3_G_ROUNDS; ++r) asm_load4(pg[r], g_off(r, a), a.grs);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < V3_X_ROUNDS; ++r) { asm volatile("" : "+v"(px[r])); store_x(r, 0); }
+#pragma unroll
+            for (int r = 0; r < V3_G_ROUNDS; ++r) { asm volatile("" : "+v"(pg[r])); store_g(r, 0); }
+        }
+        {
+            const TileAt a = tile_at(1);
+#pragma unroll
+            for (int r = 0; r < V3_X_ROUNDS; ++r) asm_load4(px[r], x_off(r, a), a.xrs);
+#pragma unroll
+            for (int r = 0; r < V3_G_ROUNDS; ++r) asm_load4(pg[r], g_off(r, a), a.grs);
+        }
+        lds_barrier();                                                                     // (P)
+        V3_TICK(1);
+#pragma unroll 1
+        for (int k = 0; k < my_tiles; ++k) {
+            // tile k+1: registers -> the other buffer; each register is refilled with tile k+2 right after its split
+            const TileAt a = tile_at(k + 2);
+            const int nb = ((k + 1) & 1) * V3_BUF;
+#pragma unroll
+            for (int r = 0; r < V3_X_ROUNDS; ++r) {
+                asm_wait(px[r]);
+                store_x(r, nb);
+                asm_load4(px[r], x_off(r, a), a.xrs);
+                __builtin_amdgcn_sched_barrier(0);   // one round at a time, in order (the wait counts depend on it)
+            }
+#pragma unroll
+            for (int r = 0; r < V3_G_ROUNDS; ++r) {
+                asm_wait(pg[r]);
+                store_g(r, nb);
+                asm_load4(pg[r], g_off(r, a), a.grs);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            V3_TICK(0);
+            lds_barrier();
+            V3_TICK(1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef XSD_DIAG
+        if (stamp && tid == 0) { atomicAdd(&P.dbg[8], st[0]); atomicAdd(&P.dbg[11], st[1]); }
+#endif
+        // tiles past the end were staged as zeros (empty descriptors): bsum took 0 from them; tile 0 and 1 were counted once each
+    } else {
+        // ============================== MFMA waves ==============================
+        const int wv = wid - 4;        // which seven of the 27 units: u = 7 wv .. 7 wv + 6; u / 9 = product (0 Xh*Gh, 1 Xh*Gl, 2 Xl*Gh), u % 9 = tap
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+        // per-lane base of the transposing reads: lane i of a 16-lane group addresses block row q = i>>2 (pixel) and
+        // columns 4p..4p+3 (p = i&3) of channel group (lane>>4)&1; the lane half h selects pixels +8.
+        const int i16 = lane & 15;
+        const int lane_off = (8 * h + (i16 >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (i16 & 3) * 8;
+        lds_barrier();                                                                     // (P)
+        V3_TICK(1);
+        // one instantiation per wave (the unit table is a compile-time function of the wave index)
+        auto walk = [&](auto WV) {
+            constexpr int w = decltype(WV)::value;
+            constexpr int u0 = 7 * w, nu = (w == 3 ? 6 : 7);
+            constexpr bool need_g0 = true;                                  // every wave has an hh or an lh unit
+            constexpr bool need_g1 = (u0 < 18 && u0 + nu > 9);              // some hl unit (u in 9..17)
+#pragma unroll 1
+            for (int k = 0; k < my_tiles; ++k) {
+                const char* xb = smem + (k & 1) * V3_BUF + lane_off;                       // + term image + ((row+dy)*34 + dx + 16*mf) * 64
+                const char* gb = smem + (k & 1) * V3_BUF + V3_G_OFF + lane_off;            // + term image + (row*32 + 16*mf) * 64
+                // 8 steps of 16 pixels (tile row r = st >> 1, pixel half mf = st & 1); the fragments of step st+1 are requested
+                // before the MFMAs of step st
+                f16x8 xf[2][NU], gf[2][2];
+                auto load_step = [&](int st, f16x8 (&x)[NU], f16x8 (&g)[2]) {
+                    const int r = st >> 1, mf = st & 1;
+                    if (need_g0) g[0] = v3_tr_frag(gb, (r * TILE_W + 16 * mf) * 64);
+                    if (need_g1) g[1] = v3_tr_frag(gb, V3_GT + (r * TILE_W + 16 * mf) * 64);
+#pragma unroll
+                    for (int q = 0; q < nu; ++q) {
+                        const int u = u0 + q, prod = u / 9, tap = u % 9, dy = tap / 3, dx = tap % 3;
+                        x[q] = v3_tr_frag(xb, (prod == 2 ? V3_XT : 0) + ((r + dy) * HALO_W + dx + 16 * mf) * 64);
+                    }
+                };
+                load_step(0, xf[0], gf[0]);
+#pragma unroll
+                for (int st = 0; st < 8; ++st) {
+                    if (st + 1 < 8) load_step(st + 1, xf[(st + 1) & 1], gf[(st + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);   // the requests go out BEFORE this step's MFMAs
+#pragma unroll
+                    for (int q = 0; q < nu; ++q) {
+                        const int prod = (u0 + q) / 9;
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[st & 1][q], gf[st & 1][prod == 1 ? 1 : 0], acc[q], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                V3_TICK(0);
+                lds_barrier();
+                V3_TICK(1);
+            }
+        };
+        if (wv == 0) walk(std::integral_constant<int, 0>{});
+        else if (wv == 1) walk(std::integral_constant<int, 1>{});
+        else if (wv == 2) walk(std::integral_constant<int, 2>{});
+        else walk(std::integral_constant<int, 3>{});
+#ifdef XSD_DIAG
+        if (stamp && tid == V3_LT) { atomicAdd(&P.dbg[9], st[0]); atomicAdd(&P.dbg[10], st[1]); atomicAdd(&P.dbg[13], (unsigned long long)my_tiles); }
+#endif
+    }
+
+    // ---- final reduction through LDS: every accumulator into its own 4 KiB slab (slab = unit number), then per tap the
+    // weighted sum hh + 2^-11 (hl + lh), un-scaled (a power of two: exact), in a fixed order (bitwise reproducible)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    float* outp = P.partial + ((((long long)part * P.n_g + n) * P.n_in + j) * 9) * 1024;
+    if (!loader) {
+        const int wv = wid - 4;
+#pragma unroll
+        for (int q = 0; q < NU; ++q) {
+            if (7 * wv + q < 27) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ci = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    red[(7 * wv + q) * 1024 + ci * 32 + l31] = acc[q][i];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 9 * 1024; e += V3_THREADS) {
+        const int tap = e >> 10, el = e & 1023;
+        const float hh = red[tap * 1024 + el], hl = red[(9 + tap) * 1024 + el], lh = red[(18 + tap) * 1024 + el];
+        outp[e] = (hh + (hl + lh) * 0x1p-11f) * inv_s;
+    }
+    __syncthreads();
+    if (j == 0) { // bias gradient: staging thread lt staged channels 4*(lt&7)..+3 of the G tiles
+        if (loader) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[tid * 4 + i] = bsum[i];
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int q = tid >> 2, i = tid & 3;
+            float sacc = 0.f;
+            for (int w = 0; w < V3_LT / 8; ++w) sacc += red[(w * 8 + q) * 4 + i];
+            P.bias_partial[((long long)part * P.n_g + n) * 32 + tid] = sacc;
+        }
+    }
+}
+
+hipError_t launch_wgrad_h2x(const WgradParams& p, hipStream_t stream)
+{
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h2x_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    if (p.nparts & 7) return hipErrorInvalidValue;
+    // 32-bit byte offsets inside one batch slice of a plane (buffer loads); xsd_forward rejects larger images as well
+    for (int i = 0; i < p.n_in; ++i) if ((long long)p.H * p.x[i].rs * 4 >= (1ll << 31)) return hipErrorInvalidValue;
+    for (int i = 0; i < p.n_g; ++i) if ((long long)p.H * p.g[i].rs * 4 >= (1ll << 31)) return hipErrorInvalidValue;
+    const dim3 g(p.nparts * p.n_in * p.n_g), b(V3_THREADS);
+    hipLaunchKernelGGL(wgrad_h2x_kernel, g, b, V3_LDS_BYTES, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace xsd

@@ -44,6 +44,7 @@ hipError_t launch_conv3x3_s3(const ConvParams& p, hipStream_t stream);
 hipError_t launch_conv3x3_s3x(const ConvParams& p, hipStream_t stream);
 hipError_t launch_wgrad_s3(const WgradParams& p, hipStream_t stream);
 hipError_t launch_wgrad_s3x(const WgradParams& p, hipStream_t stream);
+hipError_t launch_wgrad_h2x(const WgradParams& p, hipStream_t stream);
 hipError_t launch_plane_convert(const float* in, float* out, long long npix, int to_p16, hipStream_t s);
 hipError_t launch_plane_amax(const PlaneIn& v, int B, int H, int W, float* slot, hipStream_t s);   // math mode 4
 hipError_t launch_buffer_amax(const float* v, long long n, float* slot, hipStream_t s);

@@ -157,6 +157,13 @@ static hipError_t launch_wgrad_bf16x6(int ablate, const WgradParams& p, hipStrea
 {
     return wgrad_bf16x6_unified(ablate) ? launch_wgrad_s3(p, s) : launch_wgrad_s3x(p, s);
 }
+// weight gradient of the split modes: mode 4 (f16x3) has its own role-split kernel (one workgroup per CU); diagnostic ablate
+// bit 22 runs mode 3's kernel instead
+static int wgrad_split_parts(int math, int ablate, int nparts) { return (math == 4 && !(ablate & (1 << 22))) ? nparts : wgrad_bf16x6_parts(ablate, nparts); }
+static hipError_t launch_wgrad_split(int math, int ablate, const WgradParams& p, hipStream_t s)
+{
+    return (math == 4 && !(ablate & (1 << 22))) ? launch_wgrad_h2x(p, s) : launch_wgrad_bf16x6(ablate, p, s);
+}
 
 static hipError_t prof_launch(xsd_engine* e, int klass, double flop, double bytes, hipStream_t s, const std::function<hipError_t()>& f)
 {
@@ -356,9 +363,14 @@ struct Builder {
         memset(&wp, 0, sizeof(wp));
         wp.B = B; wp.H = H << level; wp.W = W << level;
         wp.tilesX = (wp.W + TILE_W - 1) / TILE_W; wp.tilesY = (wp.H + TILE_H - 1) / TILE_H;
-        wp.n_in = (int)xs.size(); wp.n_g = (int)gs.size(); wp.nparts = e->math >= 3 ? wgrad_bf16x6_parts(e->ablate, e->nparts) : e->nparts;
+        wp.n_in = (int)xs.size(); wp.n_g = (int)gs.size(); wp.nparts = e->math >= 3 ? wgrad_split_parts(e->math, e->ablate, e->nparts) : e->nparts;
         for (size_t i = 0; i < xs.size(); ++i) wp.x[i] = xs[i];
         for (size_t i = 0; i < gs.size(); ++i) wp.g[i] = gs[i];
+        std::vector<Launch> pre;     // math mode 4: reductions for planes nobody has reported yet
+        if (e->math == 4) {
+            for (size_t i = 0; i < xs.size(); ++i) wp.amax_x[i] = slot_of(xs[i], wp.H, wp.W, pre);
+            for (size_t i = 0; i < gs.size(); ++i) wp.amax_g[i] = slot_of(gs[i], wp.H, wp.W, pre);
+        }
         WgradReduceParams rp;
         memset(&rp, 0, sizeof(rp));
         rp.nparts = wp.nparts; rp.n_in = wp.n_in; rp.n_g = wp.n_g; rp.cin_total = cw.cin; rp.cout_total = cw.cout;
@@ -367,12 +379,13 @@ struct Builder {
         const double px = (double)wp.B * wp.H * wp.W;
         const double flop = 2.0 * 9 * 32 * 32 * wp.n_in * wp.n_g * px;
         const double bytes = 128.0 * (wp.n_in + wp.n_g) * px; // SURVEY 8(d) rule: every X plane and every G plane once (the kernel itself re-reads G once per X plane)
-        ops.push_back([eng, wp, rp, w_off, b_off, flop, bytes](hipStream_t s) mutable {
+        ops.push_back([eng, wp, rp, pre, w_off, b_off, flop, bytes](hipStream_t s) mutable {
+            for (auto& f : pre) { hipError_t perr = f(s); if (perr != hipSuccess) return perr; }
             wp.partial = eng->wg_partial; wp.bias_partial = eng->wg_bias_partial;
             rp.partial = eng->wg_partial; rp.bias_partial = eng->wg_bias_partial;
             rp.dw = eng->b_grads + w_off; rp.db = eng->b_grads + b_off;
             wp.zero = eng->zero_page; wp.ablate = eng->ablate; wp.dbg = eng->dbg; rp.p16 = eng->math == 2;
-            hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return eng->math >= 3 ? launch_wgrad_bf16x6(eng->ablate, wp, s) : eng->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, eng->math, s); });
+            hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return eng->math >= 3 ? launch_wgrad_split(eng->math, eng->ablate, wp, s) : eng->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, eng->math, s); });
             if (err != hipSuccess) return err;
             return launch_wgrad_reduce(rp, s);
         });
@@ -1093,11 +1106,18 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
     hipError_t err = run_conv(e, p, s);
     if (err == hipSuccess) {
         WgradParams wp; memset(&wp, 0, sizeof(wp));
-        wp.B = B; wp.H = H; wp.W = W; wp.tilesX = p.tilesX; wp.tilesY = p.tilesY; wp.n_in = n_in; wp.n_g = 1; wp.nparts = e->math >= 3 ? wgrad_bf16x6_parts(e->ablate, e->nparts) : e->nparts;
+        wp.B = B; wp.H = H; wp.W = W; wp.tilesX = p.tilesX; wp.tilesY = p.tilesY; wp.n_in = n_in; wp.n_g = 1; wp.nparts = e->math >= 3 ? wgrad_split_parts(e->math, e->ablate, e->nparts) : e->nparts;
         for (int i = 0; i < n_in; ++i) wp.x[i] = b.std_in(ins[i], 0);
         wp.g[0] = b.std_in(g, 0);
         wp.partial = e->wg_partial; wp.bias_partial = e->wg_bias_partial; wp.zero = e->zero_page;
-        err = e->math >= 3 ? launch_wgrad_bf16x6(e->ablate, wp, s) : e->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, e->math, s);
+        if (e->math == 4) {   // test hook: reduce the operands' max |x| here (slots at the end of the array, after run_conv's)
+            float* t = e->amax + xsd_engine::AMAX_CAP - 16;
+            err = hipMemsetAsync(t, 0, 8 * sizeof(float), s);
+            for (int i = 0; i < n_in && err == hipSuccess; ++i) { err = launch_plane_amax(wp.x[i], B, H, W, t + i, s); wp.amax_x[i] = t + i; }
+            if (err == hipSuccess) { err = launch_plane_amax(wp.g[0], B, H, W, t + 5, s); wp.amax_g[0] = t + 5; }
+        }
+        if (err == hipSuccess)
+            err = e->math >= 3 ? launch_wgrad_split(e->math, e->ablate, wp, s) : e->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, e->math, s);
         if (err == hipSuccess) {
             WgradReduceParams rp; memset(&rp, 0, sizeof(rp));
             rp.partial = e->wg_partial; rp.bias_partial = e->wg_bias_partial; rp.nparts = wp.nparts; rp.n_in = n_in; rp.n_g = 1;
