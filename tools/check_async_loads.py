@@ -54,7 +54,7 @@ def check(asm_text, NLOADS=15):
         op = l.split()[0]
         if op.startswith(("global_load", "buffer_load")):
             events.append((i, "load", regs_of(l.split(",")[0])))
-        elif re.match(r"s_waitcnt vmcnt\(1[0-9]\)$", l):
+        elif re.match(r"s_waitcnt vmcnt\([1-9][0-9]*\)$", l):      # a counted wait (its count is checked below); vmcnt(0) is a drain
             events.append((i, "wait", None))
         elif op.startswith(("global_", "flat_", "buffer_", "scratch_")) or (op == "s_waitcnt" and "vmcnt" in l):
             raise AssertionError("foreign vector-memory instruction in the staging loop: " + l)

@@ -1,12 +1,12 @@
 // wgrad_h2x.hip -- math mode 4 ("f16x3"): weight gradient of the 3x3 convs over fp32 planes with the two-term fp16 arithmetic
-// of conv3x3_h2x.hip; role-split workgroup as in wgrad_s3x.hip (4 staging + 4 MFMA waves, one workgroup per CU, 4 x 32-pixel
+// of conv3x3_h2x.hip; role-split workgroup in the manner of wgrad_s3x.hip (here 4 staging + 8 MFMA waves, one workgroup per CU, 4 x 32-pixel
 // tiles, two LDS buffers, one barrier per tile; read that file for the staging scheme).  Replaces autograd's conv
 // weight-gradient for the reference's nn.Conv2d(32k -> 32n, 3,1,1) layers (rrdb_blocks.py:27-31; generator_rrdb.py:38-44,95,101):
 //     dW[co][ci][tap] = sum_{b,y,x} G[b,y,x,co] * X[b,y+dy-1,x+dx-1,ci],   db[co] = sum G[..,co]
 // Arithmetic: X and G are scaled by powers of two from their max |x| slots and split into h + l * 2^-11 (xsd_split.h); the
 // product is Xh*Gh + (Xh*Gl + Xl*Gh) * 2^-11: three v_mfma_f32_32x32x16_f16 per (16 pixels, tap) instead of six bf16 ones.
 // The three products carry different weights, so they need their own accumulators: 27 32x32 accumulators (9 taps x {hh, hl, lh})
-// do not fit one wave.  The 27 single-MFMA "units" are dealt 7/7/7/6 to the four MFMA waves; each wave walks ALL four rows of
+// do not fit one wave.  The 27 single-MFMA "units" are dealt 4,4,4,3,3,3,3,3 to eight MFMA waves (7,7,7,6 per SIMD); each wave walks ALL four rows of
 // the tile for its units (every wave reads a different subset of the fragments: the LDS read volume stays what it was), and the
 // weighted sum hh + 2^-11 (hl + lh), un-scaled exactly, is formed in the final fixed-order reduction.
 // LDS: four images [pixel][32 x f16] per buffer (X_h, X_l over the 6 x 34 halo, G_h, G_l): 42,496 B, two buffers.
@@ -24,15 +24,20 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int V3_TH = 4;                                              // tile rows = MFMA waves
-constexpr int V3_LT = 256;                                            // staging threads (waves 0..3)
-constexpr int V3_THREADS = V3_LT + 64 * V3_TH;                        // 512
+constexpr int V3_TH = 4;                                              // tile rows
+constexpr int V3_MW = 8;                                              // MFMA waves: the 27 accumulators dealt 4,4,4,3,3,3,3,3
+#ifndef V3_LWAVES
+#define V3_LWAVES 4     // staging waves, one per SIMD, beside two MFMA waves per SIMD (12 waves, 168 registers).  Eight staging
+#endif                  // waves (16 waves, 128 registers; -DV3_LWAVES=8) measured 9 % slower on one device: the staging side is
+                        // bound by the CU's load path (42 KB per tile = 12-13 B/clk), not by vector issue.
+constexpr int V3_LT = 64 * V3_LWAVES;                                 // staging threads (waves 0 .. V3_LWAVES-1)
+constexpr int V3_THREADS = V3_LT + 64 * V3_MW;                        // 768
 constexpr int V3_HPX = (V3_TH + 2) * HALO_W;                          // 204 halo pixels
 constexpr int V3_X_SLOTS = V3_HPX * 8;                                // 1632 (pixel, channel quad) slots
-constexpr int V3_X_ROUNDS = (V3_X_SLOTS + V3_LT - 1) / V3_LT;         // 7
+constexpr int V3_X_ROUNDS = (V3_X_SLOTS + V3_LT - 1) / V3_LT;         // 7 (4 with eight staging waves)
 constexpr int V3_G_SLOTS = V3_TH * TILE_W * 8;                        // 1024
-constexpr int V3_G_ROUNDS = V3_G_SLOTS / V3_LT;                       // 4
-constexpr int V3_NL = V3_X_ROUNDS + V3_G_ROUNDS;                      // 11 loads per tile and staging thread
+constexpr int V3_G_ROUNDS = V3_G_SLOTS / V3_LT;                       // 4 (2)
+constexpr int V3_NL = V3_X_ROUNDS + V3_G_ROUNDS;                      // 11 (6) loads per tile and staging thread
 constexpr int V3_XT = V3_HPX * 64;                                    // 13,056 B per X term image
 constexpr int V3_GT = V3_TH * TILE_W * 64;                            // 8,192 B per G term image
 constexpr int V3_G_OFF = 2 * V3_XT;                                   // 26,112
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wid < 4;       // wave-uniform role
+    const bool loader = wid < V3_LWAVES;   // wave-uniform role
     const int h = lane >> 5;
     const int l31 = lane & 31;
 
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
     }
     const float inv_s = inv_sx * inv_sg;
 
-    constexpr int NU = 7;              // accumulators ("units") per MFMA wave: 27 = 7 + 7 + 7 + 6
+    constexpr int NU = 4;              // accumulators ("units") per MFMA wave: 27 = 4 + 4 + 4 + 3 + 3 + 3 + 3 + 3
     f32x16 acc[NU];
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f}; // staging thread: its 4 channels (lt & 7) of the G tiles it stages
 
@@ -134,8 +139,9 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             ggx[r] = p & 31;
         }
         const int lds0 = lt * 8;
-        const bool live6 = 6 * V3_LT + lt < V3_X_SLOTS;          // last X round: 96 live threads, the others write a sink
-        static_assert(V3_X_ROUNDS == 7, "sink round");
+        constexpr int RL = V3_X_ROUNDS - 1;                      // last X round: only part of the threads have a slot,
+        const bool live6 = RL * V3_LT + lt < V3_X_SLOTS;         // the others write a sink
+
 
         f32x4 px[V3_X_ROUNDS] = {};
         f32x4 pg[V3_G_ROUNDS] = {};
@@ -150,8 +156,13 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
         auto asm_load4 = [&](f32x4& dst, int off, const i32x4& rs) {
             asm volatile("buffer_load_dwordx4 %[d], %[o], %[r], 0 offen" : [d] "+v"(dst) : [o] "v"(off), [r] "s"(rs) : "memory");
         };
+#if V3_LWAVES == 8
+        auto asm_wait = [&](f32x4& v) { asm volatile("s_waitcnt vmcnt(5)" : "+v"(v) :: "memory"); };
+        static_assert(V3_NL == 6, "the counted wait is vmcnt(V3_NL - 1)");
+#else
         auto asm_wait = [&](f32x4& v) { asm volatile("s_waitcnt vmcnt(10)" : "+v"(v) :: "memory"); };
         static_assert(V3_NL == 11, "the counted wait is vmcnt(V3_NL - 1)");
+#endif
 
         struct TileAt { i32x4 xrs, grs; int xorg, gorg, x0; };
         auto tile_at = [&](int k) {        // descriptors and origin offsets of this workgroup's k-th tile (empty past the end)
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             u32x2 hi, lo;
             if (abl & 1) { hi[0] = __float_as_uint(px[r][0]); hi[1] = __float_as_uint(px[r][1]); lo[0] = __float_as_uint(px[r][2]); lo[1] = __float_as_uint(px[r][3]); }
             else split2_f16x4(px[r], sx, hi, lo);
-            char* d = smem + ((r == 6 && !live6) ? V3_SINK + (lt & 63) * 8 : buf + lds0 + r * (V3_LT * 8));
+            char* d = smem + ((r == RL && !live6) ? V3_SINK + (lt & 63) * 8 : buf + lds0 + r * (V3_LT * 8));
             if (abl & 2) { asm volatile("" :: "v"(hi), "v"(lo), "v"(d)); return; }   // diag: no LDS writes
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + V3_XT) = lo;
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
         // tiles past the end were staged as zeros (empty descriptors): bsum took 0 from them; tile 0 and 1 were counted once each
     } else {
         // ============================== MFMA waves ==============================
-        const int wv = wid - 4;        // which seven of the 27 units: u = 7 wv .. 7 wv + 6; u / 9 = product (0 Xh*Gh, 1 Xh*Gl, 2 Xl*Gh), u % 9 = tap
+        const int wv = wid - V3_LWAVES;        // which of the 27 units (4,4,4,3,3,3,3,3 per wave); u / 9 = product (0 Xh*Gh, 1 Xh*Gl, 2 Xl*Gh), u % 9 = tap
 #pragma unroll
         for (int k = 0; k < NU; ++k)
 #pragma unroll
@@ -264,9 +275,9 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
         // one instantiation per wave (the unit table is a compile-time function of the wave index)
         auto walk = [&](auto WV) {
             constexpr int w = decltype(WV)::value;
-            constexpr int u0 = 7 * w, nu = (w == 3 ? 6 : 7);
-            constexpr bool need_g0 = true;                                  // every wave has an hh or an lh unit
+            constexpr int u0 = w < 3 ? 4 * w : 12 + 3 * (w - 3), nu = w < 3 ? 4 : 3;   // waves w and w+4 share a SIMD: 7, 7, 7, 6 MFMAs per step
             constexpr bool need_g1 = (u0 < 18 && u0 + nu > 9);              // some hl unit (u in 9..17)
+            constexpr bool need_g0x = (u0 < 9 || u0 + nu > 18);            // some hh or lh unit
 #pragma unroll 1
             for (int k = 0; k < my_tiles; ++k) {
                 const char* xb = smem + (k & 1) * V3_BUF + lane_off;                       // + term image + ((row+dy)*34 + dx + 16*mf) * 64
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
                 f16x8 xf[2][NU], gf[2][2];
                 auto load_step = [&](int st, f16x8 (&x)[NU], f16x8 (&g)[2]) {
                     const int r = st >> 1, mf = st & 1;
-                    if (need_g0) g[0] = v3_tr_frag(gb, (r * TILE_W + 16 * mf) * 64);
+                    if (need_g0x) g[0] = v3_tr_frag(gb, (r * TILE_W + 16 * mf) * 64);
                     if (need_g1) g[1] = v3_tr_frag(gb, V3_GT + (r * TILE_W + 16 * mf) * 64);
 #pragma unroll
                     for (int q = 0; q < nu; ++q) {
@@ -301,10 +312,16 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
                 V3_TICK(1);
             }
         };
-        if (wv == 0) walk(std::integral_constant<int, 0>{});
-        else if (wv == 1) walk(std::integral_constant<int, 1>{});
-        else if (wv == 2) walk(std::integral_constant<int, 2>{});
-        else walk(std::integral_constant<int, 3>{});
+        switch (wv) {
+        case 0: walk(std::integral_constant<int, 0>{}); break;
+        case 1: walk(std::integral_constant<int, 1>{}); break;
+        case 2: walk(std::integral_constant<int, 2>{}); break;
+        case 3: walk(std::integral_constant<int, 3>{}); break;
+        case 4: walk(std::integral_constant<int, 4>{}); break;
+        case 5: walk(std::integral_constant<int, 5>{}); break;
+        case 6: walk(std::integral_constant<int, 6>{}); break;
+        default: walk(std::integral_constant<int, 7>{}); break;
+        }
 #ifdef XSD_DIAG
         if (stamp && tid == V3_LT) { atomicAdd(&P.dbg[9], st[0]); atomicAdd(&P.dbg[10], st[1]); atomicAdd(&P.dbg[13], (unsigned long long)my_tiles); }
 #endif
@@ -316,14 +333,15 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
     float* red = reinterpret_cast<float*>(smem);
     float* outp = P.partial + ((((long long)part * P.n_g + n) * P.n_in + j) * 9) * 1024;
     if (!loader) {
-        const int wv = wid - 4;
+        const int wv = wid - V3_LWAVES;
+        const int ub = wv < 3 ? 4 * wv : 12 + 3 * (wv - 3), un = wv < 3 ? 4 : 3;
 #pragma unroll
         for (int q = 0; q < NU; ++q) {
-            if (7 * wv + q < 27) {
+            if (q < un) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int ci = (i & 3) + 8 * (i >> 2) + 4 * h;
-                    red[(7 * wv + q) * 1024 + ci * 32 + l31] = acc[q][i];
+                    red[(ub + q) * 1024 + ci * 32 + l31] = acc[q][i];
                 }
             }
         }

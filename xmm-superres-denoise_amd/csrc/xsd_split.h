@@ -56,25 +56,51 @@ __device__ __forceinline__ void split3_f32x4(const split_f32x4& a, split_u32x2& 
 // falls into the fp16 subnormals before h does).  xs = h + l * 2^-11 up to 2^-22 |xs| (half an ulp of l), i.e. 22-23 of
 // fp32's 24 significant bits; the product of two such operands is taken as h*h + (h*l + l*h) * 2^-11 (three fp16 MFMAs,
 // the two cross products into a second accumulator).  Network-level error against float64: tools/sim_split3.py and
-// tests/test_hip_precision.py.  20 VALU per float4.
+// tests/test_hip_precision.py.  12 VALU per float4.
 typedef _Float16 split_f16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void split2_f16_pair(float x0, float x1, float s, unsigned int& h, unsigned int& l)
 {
-    const float a0 = x0 * s, a1 = x1 * s;
-    split_f32x2 a; a[0] = a0; a[1] = a1;
-    const split_f16x2 hh = __builtin_convertvector(a, split_f16x2);          // v_cvt_pk_f16_f32 (RNE)
-    h = __builtin_bit_cast(unsigned int, hh);
-    const float r0 = split_sub(a0, (float)hh[0]), r1 = split_sub(a1, (float)hh[1]);   // exact
-    split_f32x2 r; r[0] = r0 * 2048.f; r[1] = r1 * 2048.f;
-    l = __builtin_bit_cast(unsigned int, __builtin_convertvector(r, split_f16x2));
+    // Mixed-precision fma instructions do scale, convert and subtract in one step each (12 VALU per float4 instead of the 20
+    // of v_mul + v_cvt_pk_f16_f32 + v_cvt_f32_f16 + v_sub + v_mul + v_cvt_pk): v_fma_mixlo/hi_f16 write f16(a * b + c) (one
+    // RNE rounding of the exact fp32 product) into the low / high half of a register, v_fma_mix_f32 takes the f16 half of h
+    // as its addend directly.  Same values as the long form, bit for bit.
+    // (one asm statement: between separate statements hipcc pads every output with an s_nop)
+    unsigned int hh, ll;
+    float r0, r1;
+    const float k = 2048.f;
+    asm("v_fma_mixlo_f16 %[h], %[x0], %[s], 0\n\t"
+        "v_fma_mixhi_f16 %[h], %[x1], %[s], 0\n\t"
+        "v_fma_mix_f32 %[r0], %[x0], %[s], -%[h] op_sel_hi:[0,0,1]\n\t"                  // x0*s - h.lo (exact)
+        "v_fma_mix_f32 %[r1], %[x1], %[s], -%[h] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"   // x1*s - h.hi
+        "v_fma_mixlo_f16 %[l], %[r0], %[k], 0\n\t"
+        "v_fma_mixhi_f16 %[l], %[r1], %[k], 0"
+        : [h] "=&v"(hh), [l] "=&v"(ll), [r0] "=&v"(r0), [r1] "=&v"(r1)
+        : [x0] "v"(x0), [x1] "v"(x1), [s] "s"(s), [k] "s"(k));
+    h = hh;
+    l = ll;
 }
 
 __device__ __forceinline__ void split2_f16x4(const split_f32x4& a, float s, split_u32x2& hi, split_u32x2& lo)
 {
-    unsigned int h0, l0, h1, l1;
-    split2_f16_pair(a[0], a[1], s, h0, l0);
-    split2_f16_pair(a[2], a[3], s, h1, l1);
+    // both pairs in one statement, interleaved: two independent dependency chains for the in-order staging wave
+    unsigned int h0, h1, l0, l1;
+    float r0, r1, r2, r3;
+    const float k = 2048.f;
+    asm("v_fma_mixlo_f16 %[h0], %[x0], %[s], 0\n\t"
+        "v_fma_mixlo_f16 %[h1], %[x2], %[s], 0\n\t"
+        "v_fma_mixhi_f16 %[h0], %[x1], %[s], 0\n\t"
+        "v_fma_mixhi_f16 %[h1], %[x3], %[s], 0\n\t"
+        "v_fma_mix_f32 %[r0], %[x0], %[s], -%[h0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %[r2], %[x2], %[s], -%[h1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %[r1], %[x1], %[s], -%[h0] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %[r3], %[x3], %[s], -%[h1] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %[l0], %[r0], %[k], 0\n\t"
+        "v_fma_mixlo_f16 %[l1], %[r2], %[k], 0\n\t"
+        "v_fma_mixhi_f16 %[l0], %[r1], %[k], 0\n\t"
+        "v_fma_mixhi_f16 %[l1], %[r3], %[k], 0"
+        : [h0] "=&v"(h0), [h1] "=&v"(h1), [l0] "=&v"(l0), [l1] "=&v"(l1), [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3)
+        : [x0] "v"(a[0]), [x1] "v"(a[1]), [x2] "v"(a[2]), [x3] "v"(a[3]), [s] "s"(s), [k] "s"(k));
     hi[0] = h0; hi[1] = h1;
     lo[0] = l0; lo[1] = l1;
 }
