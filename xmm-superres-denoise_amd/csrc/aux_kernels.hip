@@ -4,6 +4,7 @@
 #include "p16.h"
 #include "xsd_kernels.h"
 #include "xsd_aux.h"
+#include "xsd_split.h"
 
 namespace xsd {
 
@@ -443,6 +444,26 @@ __global__ void buffer_amax_kernel(const float* v, long long n, float* slot)
     atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(m));
 }
 
+// math mode 4 (f16x3): fp32 fragment-order panels [panel][s2][tap][lane][8 floats] (pack_weights_s3_kernel) -> the two-term fp16
+// image the conv kernel copies into LDS as it is: [panel][s2][tap][term h | l][lane][8 x f16], the same 36,864 B per panel.
+// One scale for the whole buffer (its max |w|, slot written by buffer_amax_kernel); thread = (panel, s2, tap, lane).
+__global__ void split_panels_f16_kernel(const float* src, unsigned int* dst, long long nfrag /* panels * 2 * 9 * 64 */, const float* amax)
+{
+    float inv;
+    const float sw = scale_for_amax(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *amax))), inv);
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < nfrag; g += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(g & 63);
+        const long long blk = g >> 6;                           // (panel, s2, tap)
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + g * 8), b = *reinterpret_cast<const f32x4*>(src + g * 8 + 4);
+        split_u32x2 ha, la, hb, lb;
+        split2_f16x4(a, sw, ha, la);
+        split2_f16x4(b, sw, hb, lb);
+        unsigned int* d = dst + blk * 512 + lane * 4;           // 2 terms x 1 KiB per block = 512 words
+        d[0] = ha[0]; d[1] = ha[1]; d[2] = hb[0]; d[3] = hb[1];
+        d[256 + 0] = la[0]; d[256 + 1] = la[1]; d[256 + 2] = lb[0]; d[256 + 3] = lb[1];
+    }
+}
+
 // fp32 plane <-> P16 plane (test hooks / debugging): thread = (pixel, 4-channel quad)
 __global__ void plane_to_p16_kernel(const float* in, float* out, long long npix)
 {
@@ -683,6 +704,12 @@ hipError_t launch_plane_amax(const PlaneIn& v, int B, int H, int W, float* slot,
 hipError_t launch_buffer_amax(const float* v, long long n, float* slot, hipStream_t s)
 {
     hipLaunchKernelGGL(buffer_amax_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, s, v, n, slot);
+    return hipGetLastError();
+}
+hipError_t launch_split_panels_f16(const float* src, void* dst, long long nfloats, const float* amax, hipStream_t s)
+{
+    const long long nfrag = nfloats / 8;
+    hipLaunchKernelGGL(split_panels_f16_kernel, dim3(grid_for(nfrag, 256)), dim3(256), 0, s, src, reinterpret_cast<unsigned int*>(dst), nfrag, amax);
     return hipGetLastError();
 }
 hipError_t launch_plane_convert(const float* in, float* out, long long npix, int to_p16, hipStream_t s)

@@ -221,14 +221,16 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
             const int t = wid * 64 + (int)__builtin_amdgcn_mbcnt_hi(all, __builtin_amdgcn_mbcnt_lo(all, 0u));
             asm_load4(pw[r], t * 16 + r * (X3_LT * 16), rs);
         };
+        // the weight half-panel arrives pre-split (the pack step writes the two-term fp16 image [tap][h | l][lane][8 x f16],
+        // 18,432 B, exactly as it lies in LDS): a staging round is a 16-byte copy, no VALU
         auto store_w_round = [&](int r, int wb) {   // wb: byte offset of the weight buffer in LDS
-            u32x2 hi, lo;
-            x3_split4(pw[r], sw, hi, lo);
-            const int s = r * X3_LT + lt;
-            const int frag = s >> 7, ln = (s >> 1) & 63, sub = s & 1;   // frag = tap
-            char* d = w_lds + wb + (s < X3_WSLOTS ? frag * 2 * 1024 + ln * 16 + sub * 8 : X3_WSINK + lane * 8);
-            *reinterpret_cast<u32x2*>(d) = hi;
-            *reinterpret_cast<u32x2*>(d + 1024) = lo;
+            unsigned int all = ~0u;
+            asm volatile("" : "+s"(all));
+            const int t = wid * 64 + (int)__builtin_amdgcn_mbcnt_hi(all, __builtin_amdgcn_mbcnt_lo(all, 0u));
+            const int sl = r * X3_LT + t;
+            const bool live = (r + 1) * X3_LT <= X3_WSLOTS || sl < X3_WSLOTS;     // (compile-time true except in the last round)
+            char* d = w_lds + wb + (live ? sl * 16 : X3_WSINK + (t & 63) * 16);
+            *reinterpret_cast<f32x4*>(d) = pw[r];
         };
 
         // prologue: half-step 0 into LDS, half-step 1 into the staging registers

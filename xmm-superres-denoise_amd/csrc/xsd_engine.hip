@@ -763,13 +763,17 @@ int xsd_pack_weights(xsd_engine* e, const float* dev_params, void* stream)
     if (!e || !dev_params) return fail(XSD_ERR_ARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
     e->params = dev_params;
-    if (e->math >= 3) {
+    if (e->math == 4) {
+        // fp32 fragment-order panels into the (otherwise unused) mode-0 buffers, max |w| of the forward and of the
+        // input-gradient panels (one power-of-two scale each), then the two-term fp16 images the conv kernel copies to LDS
+        HIPCHK(launch_pack_weights_s3(dev_params, e->descs_dev, e->ndesc, e->pk_fwd, e->pk_bwd, s));
+        HIPCHK(hipMemsetAsync(e->amax, 0, 2 * sizeof(float), s));
+        HIPCHK(launch_buffer_amax(e->pk_fwd, e->pk_floats, e->amax + 0, s));
+        HIPCHK(launch_buffer_amax(e->pk_bwd, e->pk_floats, e->amax + 1, s));
+        HIPCHK(launch_split_panels_f16(e->pk_fwd, e->pk_fwd_s, e->pk_floats, e->amax + 0, s));
+        HIPCHK(launch_split_panels_f16(e->pk_bwd, e->pk_bwd_s, e->pk_floats, e->amax + 1, s));
+    } else if (e->math == 3) {
         HIPCHK(launch_pack_weights_s3(dev_params, e->descs_dev, e->ndesc, reinterpret_cast<float*>(e->pk_fwd_s), reinterpret_cast<float*>(e->pk_bwd_s), s));
-        if (e->math == 4) {   // max |w| of the forward and of the input-gradient panels (one power-of-two scale each)
-            HIPCHK(hipMemsetAsync(e->amax, 0, 2 * sizeof(float), s));
-            HIPCHK(launch_buffer_amax(reinterpret_cast<const float*>(e->pk_fwd_s), e->pk_floats, e->amax + 0, s));
-            HIPCHK(launch_buffer_amax(reinterpret_cast<const float*>(e->pk_bwd_s), e->pk_floats, e->amax + 1, s));
-        }
     }
     else if (e->math == 2)
         HIPCHK(launch_pack_weights_p16(dev_params, e->descs_dev, e->ndesc, e->pk_fwd_s, e->pk_bwd_s, s));
@@ -992,7 +996,7 @@ int xsd_profile_read(xsd_engine* e, int klass, double* total_ms, int64_t* launch
 }
 
 // ---- single-layer test hooks ---------------------------------------------------------------------------------
-static int pack_single(const float* dev_w, int cout, int cin, float** fwd, float** bwd, int math, hipStream_t s)
+static int pack_single(const float* dev_w, int cout, int cin, float** fwd, float** bwd, int math, hipStream_t s, float* amax_slots = nullptr)
 {
     const long long n = (long long)(cout / 32) * (cin / 32) * PANEL_FLOATS;
     PackDesc d; d.src_w = 0; d.dst_fwd = 0; d.dst_bwd = 0; d.cout = cout; d.cin = cin; d.shuffle = 0; d.bwd_scale = 1.f;
@@ -1001,7 +1005,19 @@ static int pack_single(const float* dev_w, int cout, int cin, float** fwd, float
     HIPCHK(hipMalloc((void**)bwd, sizeof(float) * n));
     HIPCHK(hipMalloc((void**)&dd, sizeof(PackDesc)));
     HIPCHK(hipMemcpy(dd, &d, sizeof(d), hipMemcpyHostToDevice));
-    if (math >= 3) HIPCHK(launch_pack_weights_s3(dev_w, dd, 1, *fwd, *bwd, s));
+    if (math == 4) {   // as xsd_pack_weights: fp32 panels -> max |w| (slots CAP-4 / CAP-3 of `amax`) -> two-term fp16 images
+        float *tf = nullptr, *tb = nullptr;
+        HIPCHK(hipMalloc((void**)&tf, sizeof(float) * n));
+        HIPCHK(hipMalloc((void**)&tb, sizeof(float) * n));
+        HIPCHK(launch_pack_weights_s3(dev_w, dd, 1, tf, tb, s));
+        HIPCHK(hipMemsetAsync(amax_slots, 0, 2 * sizeof(float), s));
+        HIPCHK(launch_buffer_amax(tf, n, amax_slots + 0, s));
+        HIPCHK(launch_buffer_amax(tb, n, amax_slots + 1, s));
+        HIPCHK(launch_split_panels_f16(tf, *fwd, n, amax_slots + 0, s));
+        HIPCHK(launch_split_panels_f16(tb, *bwd, n, amax_slots + 1, s));
+        HIPCHK(hipStreamSynchronize(s));
+        hipFree(tf); hipFree(tb);
+    } else if (math == 3) HIPCHK(launch_pack_weights_s3(dev_w, dd, 1, *fwd, *bwd, s));
     else if (math == 2) HIPCHK(launch_pack_weights_p16(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
     else if (math == 1) HIPCHK(launch_pack_weights_split(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
     else HIPCHK(launch_pack_weights(dev_w, dd, 1, *fwd, *bwd, s));
@@ -1022,7 +1038,7 @@ static hipError_t run_conv(xsd_engine* e, ConvParams& p, hipStream_t s)
     p.zero = e->zero_page;
     for (int i = 0; i < (p.n_out > 1 ? p.n_out : p.n_in); ++i) p.wstep[i] = p.wpanel + (long long)i * PANEL_FLOATS;
     if (e->math == 4) {   // test hook: nobody has reported the operands' max |x| -> reduce them here (slots at the end of the array)
-        float* t = e->amax + xsd_engine::AMAX_CAP - 8;
+        float* t = e->amax + xsd_engine::AMAX_CAP - 32;    // (CAP-16.. belong to the weight-gradient hook, CAP-4 / CAP-3 to pack_single)
         hipError_t err = hipMemsetAsync(t, 0, 8 * sizeof(float), s);
         if (err != hipSuccess) return err;
         for (int i = 0; i < p.n_in; ++i) {
@@ -1030,9 +1046,7 @@ static hipError_t run_conv(xsd_engine* e, ConvParams& p, hipStream_t s)
             if (err != hipSuccess) return err;
             p.amax_in[i] = t + i;
         }
-        err = launch_buffer_amax(p.wpanel, (long long)p.n_in * p.n_out * PANEL_FLOATS, t + 5, s);
-        if (err != hipSuccess) return err;
-        p.amax_w = t + 5;
+        if (!p.amax_w) return hipErrorInvalidValue;   // set by the hook from pack_single's slots (forward or input-gradient panels)
         return launch_conv3x3_h2x(p, s);
     }
     if (e->math == 3) return launch_conv_bf16x6(e->ablate, p, s);
@@ -1046,7 +1060,7 @@ int xsd_test_conv3x3(xsd_engine* e, const float* const* in_planes, int n_in, con
     if (!e || n_in < 1 || n_in > 5 || n_out < 1 || n_out > 5 || (n_in > 1 && n_out > 1)) return fail(XSD_ERR_ARG, "bad n_in/n_out");
     hipStream_t s = (hipStream_t)stream;
     float *fwd = nullptr, *bwd = nullptr;
-    int rc = pack_single(dev_w_oihw, 32 * n_out, 32 * n_in, &fwd, &bwd, e->math, s);
+    int rc = pack_single(dev_w_oihw, 32 * n_out, 32 * n_in, &fwd, &bwd, e->math, s, e->amax + xsd_engine::AMAX_CAP - 4);
     if (rc) return rc;
     const long long npix = (long long)B * H * W;
     TmpPlanes tmp;
@@ -1063,6 +1077,7 @@ int xsd_test_conv3x3(xsd_engine* e, const float* const* in_planes, int n_in, con
     Builder b(e, B, H, W, false, 0);
     ConvParams p = b.conv_base(0);
     p.n_in = n_in; p.n_out = n_out; p.wpanel = fwd; p.bias = dev_bias;
+    p.amax_w = e->amax + xsd_engine::AMAX_CAP - 4;     // mode 4: max |w| of the forward panels (pack_single)
     for (int i = 0; i < n_in; ++i) p.in[i] = b.std_in(ins[i], 0);
     for (int j = 0; j < n_out; ++j) { b.std_out(p.out[j], outs[j], 0); p.out[j].slope = slope; }
     hipError_t err = run_conv(e, p, s);
@@ -1080,7 +1095,7 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
     if (!e || n_in < 1 || n_in > 5) return fail(XSD_ERR_ARG, "bad n_in");
     hipStream_t s = (hipStream_t)stream;
     float *fwd = nullptr, *bwd = nullptr;
-    int rc = pack_single(dev_w_oihw, 32, 32 * n_in, &fwd, &bwd, e->math, s);
+    int rc = pack_single(dev_w_oihw, 32, 32 * n_in, &fwd, &bwd, e->math, s, e->amax + xsd_engine::AMAX_CAP - 4);
     if (rc) return rc;
     const long long npix = (long long)B * H * W;
     TmpPlanes tmp;
@@ -1102,6 +1117,7 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
     Builder b(e, B, H, W, false, 0);
     ConvParams p = b.conv_base(0);
     p.n_in = 1; p.n_out = n_in; p.wpanel = bwd; p.in[0] = b.std_in(g, 0);
+    p.amax_w = e->amax + xsd_engine::AMAX_CAP - 3;     // mode 4: max |w| of the input-gradient panels
     for (int j = 0; j < n_in; ++j) b.std_out(p.out[j], dxs[j], 0);
     hipError_t err = run_conv(e, p, s);
     if (err == hipSuccess) {
