@@ -316,7 +316,7 @@ def main():
                 # split modes: `nprod` bf16 MFMAs per fp32 product -> effective matrix peak 2500 / nprod TFLOP/s
                 nprod = MATH_PRODUCTS[args.math]
                 eff_peak = BF16_MFMA_PEAK_TFLOPS / nprod
-                mf = {"achieved": tf, "peak": eff_peak, "unit": f"TFLOP/s (algorithmic fp32 FLOP; {nprod} bf16 MFMAs each)",
+                mf = {"achieved": tf, "peak": eff_peak, "unit": f"TFLOP/s (algorithmic fp32 FLOP; {nprod} {'fp16' if args.math == 'f16x3' else 'bf16'} MFMAs each)",
                       "frac": tf / eff_peak}
                 hb = {"achieved": gbs, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBPS}
                 if MATH_BOUND[args.math] == "hbm":
