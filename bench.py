@@ -11,8 +11,8 @@ Other workloads (parity-test configs, not bench lines): --workload sr_fwd (confi
 
 The headline `value` is measured in an fp32-class math mode over the full --steps/--warmup.  Default `--math f16x3`: every
 operand tensor scaled by a power of two from its max |x| and split into two fp16 terms (22-23 of fp32's 24 significant
-bits), three fp16 MFMA products per fp32 product (forward and input-gradient convs; the weight gradient runs the bf16x6
-kernel), MFMA single-rounding fp32 accumulation, fp32 planes.  tests/test_hip_precision.py measures it against float64 on
+bits), three fp16 MFMA products per fp32 product (forward, input-gradient and weight-gradient kernels), MFMA
+single-rounding fp32 accumulation, fp32 planes.  tests/test_hip_precision.py measures it against float64 on
 the goldens, a 512 x 512 four-block net and the backward pass: forward below torch's fp32 path and below this engine's
 exact-fp32 MFMA mode, backward never above the exact-fp32 MFMA mode (an fp32 fma chain) and within 2x of torch's CPU
 kernel.  `--math bf16x6` is the strict fp32-class mode (exact three-term bf16 split, six products: below BOTH yard-sticks

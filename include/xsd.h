@@ -66,8 +66,8 @@ int64_t xsd_param_count(const xsd_engine* e);
  * terms and a product is six bf16 MFMA products (dropped terms <= 2^-23 relative); v_mfma_f32_32x32x16_bf16 sums its 16
  * products and the fp32 accumulator exactly and rounds once, so against float64 this mode is at least as accurate as
  * mode 0 and as the reference's fp32 nn.Conv2d (tests/test_hip_precision.py).  Planes stay fp32.
- * 4 = "f16x3": fp32-CLASS arithmetic on the fp16 matrix cores at half the matrix work of mode 3 (forward and input-gradient
- * convs; the weight gradient runs mode 3's kernel): every operand tensor is scaled by a power of two chosen from its max |x|
+ * 4 = "f16x3": fp32-CLASS arithmetic on the fp16 matrix cores at half the matrix work of mode 3 (forward, input-gradient and
+ * weight-gradient kernels): every operand tensor is scaled by a power of two chosen from its max |x|
  * (reported by the kernel that produced it) and split into two fp16 terms (22-23 of fp32's 24 significant bits), a product
  * is three fp16 MFMA products, the epilogue undoes the scales exactly.  Against float64: forward below torch fp32 and below
  * mode 0; backward at mode 0's level (an fp32 fma chain), 1.2-1.6x torch's CPU kernel (tests/test_hip_precision.py).
