@@ -581,6 +581,9 @@ hipError_t launch_conv3x3_h2x(const ConvParams& p, hipStream_t stream)
         done = true;
     }
     if (p.n_in < 1 || p.n_out < 1 || p.n_in * p.n_out > 5 || !p.zero) return hipErrorInvalidValue;
+    // the operand scales come from these slots: an unknown maximum must not silently become "1.0" (fp16 would overflow)
+    if (!p.amax_w) return hipErrorInvalidValue;
+    for (int i = 0; i < p.n_in; ++i) if (!p.amax_in[i]) return hipErrorInvalidValue;
     const int tilesY = (p.H + X3_ROWS - 1) / X3_ROWS;
     const int ntiles = p.B * p.tilesX * tilesY;
     if (ntiles <= 0) return hipSuccess;

@@ -378,6 +378,8 @@ hipError_t launch_wgrad_h2x(const WgradParams& p, hipStream_t stream)
         done = true;
     }
     if (p.nparts & 7) return hipErrorInvalidValue;
+    for (int i = 0; i < p.n_in; ++i) if (!p.amax_x[i]) return hipErrorInvalidValue;   // operand scales: never guessed (fp16 range)
+    for (int i = 0; i < p.n_g; ++i) if (!p.amax_g[i]) return hipErrorInvalidValue;
     // 32-bit byte offsets inside one batch slice of a plane (buffer loads); xsd_forward rejects larger images as well
     for (int i = 0; i < p.n_in; ++i) if ((long long)p.H * p.x[i].rs * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     for (int i = 0; i < p.n_g; ++i) if ((long long)p.H * p.g[i].rs * 4 >= (1ll << 31)) return hipErrorInvalidValue;
