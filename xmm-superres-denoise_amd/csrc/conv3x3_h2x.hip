@@ -427,7 +427,10 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
         const float s1 = (decltype(generic)::value && !o.e1) ? 0.f : o.s1, s2v = (decltype(generic)::value && !o.e2) ? 0.f : o.s2;
         const float s3 = (decltype(generic)::value && !o.e3) ? 0.f : o.s3, msl = (decltype(generic)::value && !o.mask) ? 1.f : o.mslope;
         const float sacc = (decltype(generic)::value && !o.accumulate) ? 0.f : 1.f;
-        const float a1e = o.a1 * inv_s;     // undoes the operand scales (a power of two: exact)
+        // a1e undoes the operand scales (a power of two: exact).  Without an accumulate / e1 operand between the two factors
+        // a2 multiplies the same value and is folded in (every such launch of the engine has a2 = 1: exact there)
+        constexpr bool fold_a2 = !decltype(has_acc)::value && !decltype(has_e1)::value;
+        const float a1e = fold_a2 ? o.a1 * inv_s * o.a2 : o.a1 * inv_s;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int y = T.y0 + wv * 2 + r;
@@ -454,11 +457,11 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
                 for (int t = 0; t < 4; ++t) v[t] = (acc[r][4 * q + t] + accx[r][4 * q + t] * 0x1p-11f) * a1e;
                 if constexpr (decltype(has_acc)::value) v += sacc * va[q];
                 if constexpr (decltype(has_e1)::value) v += s1 * v1[q];
-                v *= o.a2;
+                if constexpr (!fold_a2) v *= o.a2;
                 if constexpr (decltype(has_e2)::value) v += s2v * v2[q];
                 if constexpr (decltype(has_e3)::value) v += s3 * v3[q];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = v[t] > 0.f ? v[t] : v[t] * o.slope;
+                for (int t = 0; t < 4; ++t) v[t] = __builtin_fmaxf(v[t], v[t] * o.slope);   // = v > 0 ? v : v * slope for 0 <= slope <= 1 (0.2, 0.01, 1)
                 if constexpr (decltype(has_mask)::value) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) v[t] = vm[q][t] > 0.f ? v[t] : v[t] * msl;
