@@ -3,7 +3,7 @@ csrc/conv3x3_h2x.hip, csrc/wgrad_s3x.hip, csrc/wgrad_h2x.hip).
 
 The staging loop issues its global loads and their `s_waitcnt vmcnt(14)` from inline asm, so hipcc does not know that a
 load's destination registers are written asynchronously.  That is only correct if, in the generated code,
-  * the loop holds exactly N asm loads (15 for the conv, 11 for the weight gradient), each group of m loads behind one asm wait
+  * the loop holds exactly N asm loads (15 for the conv, 11 / 19 for the weight gradients), each group of m loads behind one asm wait
     `vmcnt(N - m)` -- and no other vector-memory instruction (anything else would shift the hand-made count),
   * the destination registers of a load are touched nowhere in the loop except between its group's wait and the last
     load of the group, and not after its own reload was issued (no copy made while the load is in flight, no reuse
@@ -18,7 +18,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "xmm-superres-denoise_amd", "csrc")
-KERNELS = (("conv3x3_s3x.hip", 15), ("conv3x3_h2x.hip", 15), ("wgrad_s3x.hip", 11), ("wgrad_h2x.hip", 11))     # source, counted loads per pass of the staging loop
+KERNELS = (("conv3x3_s3x.hip", 15), ("conv3x3_h2x.hip", 15), ("wgrad_s3x.hip", 11), ("wgrad_h2x.hip", 19))     # source, counted loads per pass of the staging loop
 
 
 def regs_of(tok):
@@ -110,11 +110,16 @@ def check(asm_text, NLOADS=15):
 
 def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    for src, nloads in KERNELS:
+    kernels = KERNELS
+    extra = os.environ.get("XSD_CHECK_FLAGS", "").split()          # experiment builds: e.g. XSD_CHECK_FLAGS=-DV3_TH_ROWS=8
+    if os.environ.get("XSD_CHECK_ONLY"):                            # "wgrad_h2x.hip:19" -> that kernel with that load count
+        name, n = os.environ["XSD_CHECK_ONLY"].split(":")
+        kernels = ((name, int(n)),)
+    for src, nloads in kernels:
         with tempfile.TemporaryDirectory() as d:
             out = os.path.join(d, "k.s")
             subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",   # the flags of csrc/Makefile
-                            "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out], check=True, stderr=subprocess.DEVNULL)
+                            "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out] + extra, check=True, stderr=subprocess.DEVNULL)
             n = check(open(out).read(), nloads)
         print("%s staging loop: %d instructions, %d counted loads, destinations private to their windows" % (src, n, nloads))
 

@@ -1,15 +1,16 @@
 // wgrad_h2x.hip -- math mode 4 ("f16x3"): weight gradient of the 3x3 convs over fp32 planes with the two-term fp16 arithmetic
-// of conv3x3_h2x.hip; role-split workgroup in the manner of wgrad_s3x.hip (here 4 staging + 8 MFMA waves, one workgroup per CU, 4 x 32-pixel
+// of conv3x3_h2x.hip; role-split workgroup in the manner of wgrad_s3x.hip (here 4 staging + 8 MFMA waves, one workgroup per CU, 8 x 32-pixel
 // tiles, two LDS buffers, one barrier per tile; read that file for the staging scheme).  Replaces autograd's conv
 // weight-gradient for the reference's nn.Conv2d(32k -> 32n, 3,1,1) layers (rrdb_blocks.py:27-31; generator_rrdb.py:38-44,95,101):
 //     dW[co][ci][tap] = sum_{b,y,x} G[b,y,x,co] * X[b,y+dy-1,x+dx-1,ci],   db[co] = sum G[..,co]
 // Arithmetic: X and G are scaled by powers of two from their max |x| slots and split into h + l * 2^-11 (xsd_split.h); the
-// product is Xh*Gh + (Xh*Gl + Xl*Gh) * 2^-11: three v_mfma_f32_32x32x16_f16 per (16 pixels, tap) instead of six bf16 ones.
+// product is Xh*Gh + (Xh*Gl + Xl*Gh) * 2^-11: three fp16 MFMA products per (pixels, tap) instead of six bf16 ones, issued as
+// v_mfma_f32_16x16x32_f16 (four 16x16 tiles per 32x32 accumulator, K = the 32 pixels of a tile row).
 // The three products carry different weights, so they need their own accumulators: 27 32x32 accumulators (9 taps x {hh, hl, lh})
-// do not fit one wave.  The 27 single-MFMA "units" are dealt 4,4,4,3,3,3,3,3 to eight MFMA waves (7,7,7,6 per SIMD); each wave walks ALL four rows of
+// do not fit one wave.  The 27 single-MFMA "units" are dealt 4,4,4,3,3,3,3,3 to eight MFMA waves (7,7,7,6 per SIMD); each wave walks ALL rows of
 // the tile for its units (every wave reads a different subset of the fragments: the LDS read volume stays what it was), and the
 // weighted sum hh + 2^-11 (hl + lh), un-scaled exactly, is formed in the final fixed-order reduction.
-// LDS: four images [pixel][32 x f16] per buffer (X_h, X_l over the 6 x 34 halo, G_h, G_l): 42,496 B, two buffers.
+// LDS: four images per buffer (X_h, X_l over the 10 x 34 halo, G_h, G_l), each [channel half][pixel][16 x f16]: 76,800 B, two buffers.
 #include <type_traits>
 #include "xsd_kernels.h"
 #include "xsd_split.h"
@@ -24,27 +25,43 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int V3_TH = 4;                                              // tile rows
+#ifndef V3_SHAPE32      // -DV3_SHAPE32: the v_mfma_f32_32x32x16_f16 variant (A/B: this kernel 3.4 % FASTER per launch, the train step
+#define V3_SHAPE16 1    // 0.7 % SLOWER -- the chip is power-limited, the 16x16x32 shape draws less, and the conv launches between the
+#endif                  // weight-gradient launches run at a 2.5 % higher clock for it; two alternating pairs on one device)
+#ifndef V3_TH_ROWS
+#define V3_TH_ROWS 8     // 8-row tiles: halo 10/8 instead of 6/4 rows staged per row computed (4 rows: +6.7 % kernel time, one device)
+#endif
+constexpr int V3_TH = V3_TH_ROWS;                                     // tile rows
 constexpr int V3_MW = 8;                                              // MFMA waves: the 27 accumulators dealt 4,4,4,3,3,3,3,3
 #ifndef V3_LWAVES
 #define V3_LWAVES 4     // staging waves, one per SIMD, beside two MFMA waves per SIMD (12 waves, 168 registers).  Eight staging
 #endif                  // waves (16 waves, 128 registers; -DV3_LWAVES=8) measured 9 % slower on one device: the staging side is
-                        // bound by the CU's load path (42 KB per tile = 12-13 B/clk), not by vector issue.
+                        // bound by the CU's load path (12-13 B/clk), not by vector issue (measured with 4-row tiles).
 constexpr int V3_LT = 64 * V3_LWAVES;                                 // staging threads (waves 0 .. V3_LWAVES-1)
 constexpr int V3_THREADS = V3_LT + 64 * V3_MW;                        // 768
-constexpr int V3_HPX = (V3_TH + 2) * HALO_W;                          // 204 halo pixels
-constexpr int V3_X_SLOTS = V3_HPX * 8;                                // 1632 (pixel, channel quad) slots
-constexpr int V3_X_ROUNDS = (V3_X_SLOTS + V3_LT - 1) / V3_LT;         // 7 (4 with eight staging waves)
-constexpr int V3_G_SLOTS = V3_TH * TILE_W * 8;                        // 1024
-constexpr int V3_G_ROUNDS = V3_G_SLOTS / V3_LT;                       // 4 (2)
-constexpr int V3_NL = V3_X_ROUNDS + V3_G_ROUNDS;                      // 11 (6) loads per tile and staging thread
-constexpr int V3_XT = V3_HPX * 64;                                    // 13,056 B per X term image
-constexpr int V3_GT = V3_TH * TILE_W * 64;                            // 8,192 B per G term image
-constexpr int V3_G_OFF = 2 * V3_XT;                                   // 26,112
-constexpr int V3_BUF = V3_G_OFF + 2 * V3_GT;                          // 42,496 B per buffer
-constexpr int V3_SINK = 2 * V3_BUF;                                   // writes of exhausted slots land behind the buffers
+constexpr int V3_HPX = (V3_TH + 2) * HALO_W;                          // 340 halo pixels
+constexpr int V3_X_SLOTS = V3_HPX * 8;                                // 2720 (pixel, channel quad) slots
+constexpr int V3_X_ROUNDS = (V3_X_SLOTS + V3_LT - 1) / V3_LT;         // 11
+constexpr int V3_G_SLOTS = V3_TH * TILE_W * 8;                        // 2048
+constexpr int V3_G_ROUNDS = V3_G_SLOTS / V3_LT;                       // 8
+constexpr int V3_NL = V3_X_ROUNDS + V3_G_ROUNDS;                      // 19 loads per tile and staging thread
+constexpr int V3_XT = V3_HPX * 64;                                    // 21,760 B per X term image
+#ifdef V3_SHAPE16
+// v_mfma_f32_16x16x32_f16 variant: a term image is [channel half][pixel][16 x f16] (32-B records); the 32 lanes of a
+// transposing read then take 256 contiguous bytes (8 pixels of one channel half): conflict-free at any pixel offset.  The
+// half-image strides are = 128 mod 256 so that a staging write (lanes 0-31: 4 pixels x both halves) is conflict-free too.
+constexpr int V3_XH = V3_HPX * 32;                                    // 10,880 B per X half image (= 128 mod 256)
+constexpr int V3_GH = V3_TH * TILE_W * 32 + 128;                      // 8,320 B per G half image
+constexpr int V3_GT = 2 * V3_GH;                                      // 16,640 B per G term image
+static_assert(V3_XH % 256 == 128 && V3_GH % 256 == 128 && 2 * V3_XH == V3_XT, "half-image strides");
+#else
+constexpr int V3_GT = V3_TH * TILE_W * 64;                            // 16,384 B per G term image
+#endif
+constexpr int V3_G_OFF = 2 * V3_XT;                                   // 43,520
+constexpr int V3_BUF = V3_G_OFF + 2 * V3_GT;                          // 76,288 B per buffer
+constexpr int V3_SINK = 2 * V3_BUF;                                   // writes of exhausted slots land behind the buffers (hi at +0, lo at +512)
 constexpr int V3_RED = 27 * 4096;                                     // final reduction: one 4 KiB slab per accumulator
-constexpr int V3_LDS_BYTES = (V3_SINK + V3_XT + 2048) > V3_RED ? (V3_SINK + V3_XT + 2048) : V3_RED;   // 110,592
+constexpr int V3_LDS_BYTES = (V3_SINK + 1024) > V3_RED ? (V3_SINK + 1024) : V3_RED;     // 153,600
 static_assert(V3_LDS_BYTES <= 160 * 1024, "LDS");
 
 
@@ -68,8 +85,10 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wid < V3_LWAVES;   // wave-uniform role
+#ifndef V3_SHAPE16
     const int h = lane >> 5;
     const int l31 = lane & 31;
+#endif
 
     // 1-D grid decode as in wgrad_s3.hip: the n_in workgroups that read the SAME G tiles have linear ids 8 apart -> one XCD
     const int lin = blockIdx.x;
@@ -112,7 +131,11 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
     const float inv_s = inv_sx * inv_sg;
 
     constexpr int NU = 4;              // accumulators ("units") per MFMA wave: 27 = 4 + 4 + 4 + 3 + 3 + 3 + 3 + 3
+#ifdef V3_SHAPE16
+    f32x4 acc[NU][2][2];               // [unit][input-channel half][output-channel half]: four 16x16 tiles per unit
+#else
     f32x16 acc[NU];
+#endif
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f}; // staging thread: its 4 channels (lt & 7) of the G tiles it stages
 
     if (loader) {
@@ -138,7 +161,12 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             grel[r] = ((p >> 5) * gp.rs + (p & 31) * gp.ps + c * 4) * 4;
             ggx[r] = p & 31;
         }
+#ifdef V3_SHAPE16
+        const int lds0 = (lt >> 3) * 32 + (lt & 3) * 8;        // + ((lt >> 2) & 1) * half-image stride (X and G differ) + r * V3_LT * 4
+        const int xh0 = lds0 + ((lt >> 2) & 1) * V3_XH, gh0 = lds0 + ((lt >> 2) & 1) * V3_GH;
+#else
         const int lds0 = lt * 8;
+#endif
         constexpr int RL = V3_X_ROUNDS - 1;                      // last X round: only part of the threads have a slot,
         const bool live6 = RL * V3_LT + lt < V3_X_SLOTS;         // the others write a sink
 
@@ -156,13 +184,8 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
         auto asm_load4 = [&](f32x4& dst, int off, const i32x4& rs) {
             asm volatile("buffer_load_dwordx4 %[d], %[o], %[r], 0 offen" : [d] "+v"(dst) : [o] "v"(off), [r] "s"(rs) : "memory");
         };
-#if V3_LWAVES == 8
-        auto asm_wait = [&](f32x4& v) { asm volatile("s_waitcnt vmcnt(5)" : "+v"(v) :: "memory"); };
-        static_assert(V3_NL == 6, "the counted wait is vmcnt(V3_NL - 1)");
-#else
-        auto asm_wait = [&](f32x4& v) { asm volatile("s_waitcnt vmcnt(10)" : "+v"(v) :: "memory"); };
-        static_assert(V3_NL == 11, "the counted wait is vmcnt(V3_NL - 1)");
-#endif
+        auto asm_wait = [&](f32x4& v) { asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(v) : [n] "n"(V3_NL - 1) : "memory"); };
+        static_assert(V3_NL - 1 <= 63, "vmcnt is a 6-bit counter");
 
         struct TileAt { i32x4 xrs, grs; int xorg, gorg, x0; };
         auto tile_at = [&](int k) {        // descriptors and origin offsets of this workgroup's k-th tile (empty past the end)
@@ -193,16 +216,25 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             u32x2 hi, lo;
             if (abl & 1) { hi[0] = __float_as_uint(px[r][0]); hi[1] = __float_as_uint(px[r][1]); lo[0] = __float_as_uint(px[r][2]); lo[1] = __float_as_uint(px[r][3]); }
             else split2_f16x4(px[r], sx, hi, lo);
-            char* d = smem + ((r == RL && !live6) ? V3_SINK + (lt & 63) * 8 : buf + lds0 + r * (V3_LT * 8));
+            const bool sink = (r == RL && !live6);
+            #ifdef V3_SHAPE16
+            char* d = smem + (sink ? V3_SINK + (lt & 63) * 8 : buf + xh0 + r * (V3_LT * 4));
+#else
+            char* d = smem + (sink ? V3_SINK + (lt & 63) * 8 : buf + lds0 + r * (V3_LT * 8));
+#endif
             if (abl & 2) { asm volatile("" :: "v"(hi), "v"(lo), "v"(d)); return; }   // diag: no LDS writes
             *reinterpret_cast<u32x2*>(d) = hi;
-            *reinterpret_cast<u32x2*>(d + V3_XT) = lo;
+            *reinterpret_cast<u32x2*>(d + (sink ? 512 : V3_XT)) = lo;
         };
         auto store_g = [&](int r, int buf) {
             u32x2 hi, lo;
             if (abl & 1) { hi[0] = __float_as_uint(pg[r][0]); hi[1] = __float_as_uint(pg[r][1]); lo[0] = __float_as_uint(pg[r][2]); lo[1] = __float_as_uint(pg[r][3]); }
             else split2_f16x4(pg[r], sg, hi, lo);
+#ifdef V3_SHAPE16
+            char* d = smem + buf + V3_G_OFF + gh0 + r * (V3_LT * 4);
+#else
             char* d = smem + buf + V3_G_OFF + lds0 + r * (V3_LT * 8);
+#endif
             if (abl & 2) { asm volatile("" :: "v"(hi), "v"(lo), "v"(d)); bsum += pg[r]; return; }
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + V3_GT) = lo;
@@ -265,11 +297,21 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
 #pragma unroll
         for (int k = 0; k < NU; ++k)
 #pragma unroll
+#ifdef V3_SHAPE16
+            for (int i = 0; i < 16; ++i) acc[k][i >> 3][(i >> 2) & 1][i & 3] = 0.f;
+#else
             for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+#endif
         // per-lane base of the transposing reads: lane i of a 16-lane group addresses block row q = i>>2 (pixel) and
         // columns 4p..4p+3 (p = i&3) of channel group (lane>>4)&1; the lane half h selects pixels +8.
         const int i16 = lane & 15;
+#ifdef V3_SHAPE16
+        // 16x16x32: lane group g = lane >> 4 supplies k = 8g .. 8g+7, which this kernel maps to the pixels 4g .. 4g+3 (first
+        // read) and 16 + 4g .. 16 + 4g+3 (second read) of the 32-pixel row -- any k <-> pixel map serves, X and G use the same
+        const int lane_off = (4 * (lane >> 4) + (i16 >> 2)) * 32 + (i16 & 3) * 8;
+#else
         const int lane_off = (8 * h + (i16 >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (i16 & 3) * 8;
+#endif
         lds_barrier();                                                                     // (P)
         V3_TICK(1);
         // one instantiation per wave (the unit table is a compile-time function of the wave index)
@@ -282,7 +324,51 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             for (int k = 0; k < my_tiles; ++k) {
                 const char* xb = smem + (k & 1) * V3_BUF + lane_off;                       // + term image + ((row+dy)*34 + dx + 16*mf) * 64
                 const char* gb = smem + (k & 1) * V3_BUF + V3_G_OFF + lane_off;            // + term image + (row*32 + 16*mf) * 64
-                // 8 steps of 16 pixels (tile row r = st >> 1, pixel half mf = st & 1); the fragments of step st+1 are requested
+#ifdef V3_SHAPE16
+                // 16 steps (tile row r = st >> 1, input-channel half a = st & 1) of 32 pixels; per unit and step two MFMAs (the
+                // two output-channel halves).  The G fragments of a row are fetched with its a = 0 step and kept for a = 1;
+                // the fragments of step st+1 are requested before the MFMAs of step st
+                f16x8 xf[2][NU], gf[2][2][2];      // gf[row parity][term][output-channel half]
+                auto frag16 = [&](const char* base, int off) {
+                    typedef __attribute__((address_space(3))) s16x4* lds_p;
+                    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off));
+                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off + 16 * 32));
+                    s16x8 v;
+                    v[0] = lo4[0]; v[1] = lo4[1]; v[2] = lo4[2]; v[3] = lo4[3];
+                    v[4] = hi4[0]; v[5] = hi4[1]; v[6] = hi4[2]; v[7] = hi4[3];
+                    return __builtin_bit_cast(f16x8, v);
+                };
+                auto load_step = [&](int st, f16x8 (&x)[NU], f16x8 (&g)[2][2]) {
+                    const int r = st >> 1, a = st & 1;
+                    if (a == 0) {
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            if (need_g0x) g[0][b] = frag16(gb, b * V3_GH + r * TILE_W * 32);
+                            if (need_g1) g[1][b] = frag16(gb, V3_GT + b * V3_GH + r * TILE_W * 32);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < nu; ++q) {
+                        const int u = u0 + q, prod = u / 9, tap = u % 9, dy = tap / 3, dx = tap % 3;
+                        x[q] = frag16(xb, (prod == 2 ? V3_XT : 0) + a * V3_XH + ((r + dy) * HALO_W + dx) * 32);
+                    }
+                };
+                load_step(0, xf[0], gf[0]);
+#pragma unroll
+                for (int st = 0; st < 2 * V3_TH; ++st) {
+                    if (st + 1 < 2 * V3_TH) load_step(st + 1, xf[(st + 1) & 1], gf[((st + 1) >> 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);   // the requests go out BEFORE this step's MFMAs
+#pragma unroll
+                    for (int q = 0; q < nu; ++q) {
+                        const int prod = (u0 + q) / 9;
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            acc[q][st & 1][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[st & 1][q], gf[(st >> 1) & 1][prod == 1 ? 1 : 0][b], acc[q][st & 1][b], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#else
+                // 16 steps of 16 pixels (tile row r = st >> 1, pixel half mf = st & 1); the fragments of step st+1 are requested
                 // before the MFMAs of step st
                 f16x8 xf[2][NU], gf[2][2];
                 auto load_step = [&](int st, f16x8 (&x)[NU], f16x8 (&g)[2]) {
@@ -297,8 +383,8 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
                 };
                 load_step(0, xf[0], gf[0]);
 #pragma unroll
-                for (int st = 0; st < 8; ++st) {
-                    if (st + 1 < 8) load_step(st + 1, xf[(st + 1) & 1], gf[(st + 1) & 1]);
+                for (int st = 0; st < 2 * V3_TH; ++st) {
+                    if (st + 1 < 2 * V3_TH) load_step(st + 1, xf[(st + 1) & 1], gf[(st + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);   // the requests go out BEFORE this step's MFMAs
 #pragma unroll
                     for (int q = 0; q < nu; ++q) {
@@ -307,6 +393,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#endif
                 V3_TICK(0);
                 lds_barrier();
                 V3_TICK(1);
@@ -339,10 +426,17 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
         for (int q = 0; q < NU; ++q) {
             if (q < un) {
 #pragma unroll
+#ifdef V3_SHAPE16
+                for (int i = 0; i < 16; ++i) {      // tile (a, b), register t: input channel 16a + 4 (lane >> 4) + t, output channel 16b + (lane & 15)
+                    const int a = i >> 3, b = (i >> 2) & 1, t = i & 3;
+                    red[(ub + q) * 1024 + (16 * a + 4 * (lane >> 4) + t) * 32 + 16 * b + (lane & 15)] = acc[q][a][b][t];
+                }
+#else
                 for (int i = 0; i < 16; ++i) {
                     const int ci = (i & 3) + 8 * (i >> 2) + 4 * h;
                     red[(ub + q) * 1024 + ci * 32 + l31] = acc[q][i];
                 }
+#endif
             }
         }
     }
