@@ -50,7 +50,7 @@ def test_conv3x3_forward(eng, n_in, n_out, shape):
     assert _rel(got, ref) < eng.tol
 
 
-@pytest.mark.parametrize("n_in,shape", [(1, (1, 8, 32)), (2, (2, 19, 45)), (3, (1, 40, 33)), (5, (2, 17, 70))])
+@pytest.mark.parametrize("n_in,shape", [(1, (1, 8, 32)), (1, (3, 5, 7)), (4, (1, 9, 31)), (2, (2, 19, 45)), (3, (1, 40, 33)), (5, (2, 17, 70))])
 def test_conv3x3_backward(eng, n_in, shape):
     from xmm_superres_denoise.engine._lib import check
     B, H, W = shape

@@ -3,11 +3,14 @@ csrc/conv3x3_h2x.hip, csrc/wgrad_s3x.hip, csrc/wgrad_h2x.hip).
 
 The staging loop issues its global loads and their `s_waitcnt vmcnt(14)` from inline asm, so hipcc does not know that a
 load's destination registers are written asynchronously.  That is only correct if, in the generated code,
-  * the loop holds exactly N asm loads (15 for the conv, 11 / 19 for the weight gradients), each group of m loads behind one asm wait
-    `vmcnt(N - m)` -- and no other vector-memory instruction (anything else would shift the hand-made count),
-  * the destination registers of a load are touched nowhere in the loop except between its group's wait and the last
-    load of the group, and not after its own reload was issued (no copy made while the load is in flight, no reuse
-    as a temporary).
+  * the loop holds exactly N asm vector-memory operations (15 for the conv -- register loads and, with the weights by
+    LDS-DMA, `... lds` pieces --, 11 / 19 for the weight gradients) and no other vector-memory instruction or wait
+    (anything else would shift the hand-made count),
+  * with the operations retiring in issue order and `vmcnt(n)` returning when all but the youngest n have (the loop is
+    simulated from the state the prologue leaves), no instruction touches a load's destination registers while that
+    load is in flight (no copy, no reuse as a temporary, no reload), every wait retires exactly what is consumed before
+    the next one (no over-waiting: that would shorten the prefetch), an LDS-DMA piece has landed before the barrier,
+    and a pass leaves the loads in flight that it was entered with.
 This script compiles the kernel to assembly and verifies both; tests/test_isa.py runs it on every CPU test run.
 """
 import os
@@ -32,6 +35,7 @@ def regs_of(tok):
 
 
 def check(asm_text, NLOADS=15):
+    """NLOADS: vector-memory operations per pass of the staging loop (register loads + LDS-DMA pieces)"""
     lines = asm_text.splitlines()
     heads = [i for i, l in enumerate(lines) if "Inner Loop Header" in l]
     # the staging loop is the one that holds the asm waits
@@ -49,50 +53,42 @@ def check(asm_text, NLOADS=15):
     a, b = cand[0]
     body = [l.split(";")[0].strip() for l in lines[a:b + 1]]
     body = [l for l in body if l and not l.startswith(".") and not l.endswith(":")]
-    events = []          # (index in body, kind, regs)
-    for i, l in enumerate(body):
+
+    def is_load(l):
+        return l.split()[0].startswith(("global_load", "buffer_load"))
+
+    def is_dma(l):
+        return is_load(l) and (l.endswith(" lds") or "_load_lds_" in l)
+
+    kinds = []           # per body line: ("rload", dst, srcs) | ("dma", srcs) | ("wait", N) | ("barrier",) | ("other", regs)
+    for l in body:
         op = l.split()[0]
-        if op.startswith(("global_load", "buffer_load")):
-            events.append((i, "load", regs_of(l.split(",")[0])))
-        elif re.match(r"s_waitcnt vmcnt\([1-9][0-9]*\)$", l):      # a counted wait (its count is checked below); vmcnt(0) is a drain
-            events.append((i, "wait", None))
+        m = re.match(r"s_waitcnt vmcnt\(([1-9][0-9]*)\)$", l)      # a counted wait; vmcnt(0) would drain the prefetch
+        if is_dma(l):
+            kinds.append(("dma", regs_of(l)))
+        elif is_load(l):
+            kinds.append(("rload", regs_of(l.split(",")[0]), regs_of(l.split(",", 1)[1])))
+        elif m:
+            kinds.append(("wait", int(m.group(1))))
         elif op.startswith(("global_", "flat_", "buffer_", "scratch_")) or (op == "s_waitcnt" and "vmcnt" in l):
             raise AssertionError("foreign vector-memory instruction in the staging loop: " + l)
-    # group the events: every wait owns the loads up to the next wait
-    groups = []
-    for i, kind, regs in events:
-        if kind == "wait":
-            groups.append([i, []])
+        elif op == "s_barrier":
+            kinds.append(("barrier",))
         else:
-            assert groups, "a load precedes the first counted wait of the loop"
-            groups[-1][1].append((i, regs))
-    loads = [ld for g in groups for ld in g[1]]
-    assert len(loads) == NLOADS, "expected %d counted loads, got %d" % (NLOADS, len(loads))
-    for w, lds in groups:
-        m = len(lds)
-        assert m >= 1
-        # when the group's data is needed, the loads issued after its youngest member number NLOADS - m
-        want = "s_waitcnt vmcnt(%d)" % (NLOADS - m)
-        assert body[w].startswith(want), "wait owning %d loads must be %s, found %s" % (m, want, body[w])
-        last = lds[-1][0]
-        for _, dst in lds:
-            assert len(dst) == 4
-            for i, l in enumerate(body):
-                if w <= i <= last:
-                    continue
-                assert not (regs_of(l) & dst), "load destination v%s touched outside its window: %s" % (sorted(dst), l)
-        # inside the window a destination may be read before its own reload only
-        for k, (li, dst) in enumerate(lds):
-            for i in range(li + 1, last + 1):
-                assert not (regs_of(body[i]) & dst), "destination v%s used after its reload was issued: %s" % (sorted(dst), body[i])
-    # prologue: the 15 loads of half-step 1 are consumed by the loop's first pass -> same registers, untouched until the loop;
-    # the 15 loads of half-step 0 before them are followed by an explicit vmcnt(0) -> untouched until that wait
-    loop_dsts = [dst for _, dst in loads]
+            kinds.append(("other", regs_of(l)))
+    nvm = sum(k[0] in ("rload", "dma") for k in kinds)
+    assert nvm == NLOADS, "expected %d counted loads, got %d" % (NLOADS, nvm)
+    loop_dsts = [k[1] for k in kinds if k[0] == "rload"]
+    assert all(len(d) == 4 for d in loop_dsts)
+    assert any(k[0] == "wait" for k in kinds), "no counted wait in the loop"
+
+    # prologue: the register loads of the half-step the loop's first pass consumes -> same registers in the same order,
+    # untouched until the loop; the batch before them is followed by an explicit vmcnt(0) -> untouched until that wait
+    nreg = len(loop_dsts)
     pre = [l.split(";")[0].strip() for l in lines[:a]]
-    pl = [i for i, l in enumerate(pre) if l.startswith(("global_load_dwordx4", "buffer_load_dwordx4"))]
-    # the staging branch's prologue is the code right before the loop: its last 30 loads
-    assert len(pl) >= 2 * NLOADS
-    second, first = pl[-NLOADS:], pl[-2 * NLOADS:-NLOADS]
+    pl = [i for i, l in enumerate(pre) if l.startswith(("global_load_dwordx4", "buffer_load_dwordx4")) and not is_dma(l)]
+    assert len(pl) >= 2 * nreg
+    second, first = pl[-nreg:], pl[-2 * nreg:-nreg]
     for k, i in enumerate(second):
         dst = regs_of(pre[i].split(",")[0])
         assert dst == loop_dsts[k], "prologue load %d lands in v%s, the loop expects v%s" % (k, sorted(dst), sorted(loop_dsts[k]))
@@ -105,6 +101,41 @@ def check(asm_text, NLOADS=15):
         dst = regs_of(pre[i].split(",")[0])
         for l in pre[i + 1:w0[0]]:
             assert not (regs_of(l) & dst), "first-batch load %d destination touched before its wait: %s" % (k, l)
+
+    # the loop, simulated: vector-memory operations retire in issue order, `vmcnt(N)` returns when all but the youngest N
+    # have.  Two passes, the first entered with the prologue's second batch in flight; the state a pass leaves must be
+    # the state it was entered with.
+    queue = [("r", d) for d in loop_dsts]                             # oldest first
+    for npass in range(2):
+        entered = list(queue)
+        for i, k in enumerate(kinds):
+            inflight = set().union(*[q[1] for q in queue if q[0] == "r"]) if queue else set()
+            if k[0] == "wait":
+                n = k[1]
+                retired = queue[:max(0, len(queue) - n)]
+                assert retired, "counted wait retires nothing: " + body[i]
+                queue = queue[len(retired):]
+                # tight: everything a wait retires is consumed before the next wait (a register load by an instruction
+                # that touches its destination, an LDS-DMA piece by the barrier)
+                nxt = next((j for j in range(i + 1, len(kinds)) if kinds[j][0] == "wait"), len(kinds))
+                for q in retired:
+                    if q[0] == "r":
+                        used = any(kinds[j][0] in ("other", "rload", "dma") and (regs_of(body[j]) & q[1]) for j in range(i + 1, nxt))
+                        assert used, "%s retires the load into v%s, which is not consumed before the next wait" % (body[i], sorted(q[1]))
+                    else:
+                        assert any(kinds[j][0] == "barrier" for j in range(i + 1, nxt)), "%s retires an LDS-DMA piece early" % body[i]
+            elif k[0] == "rload":
+                assert not (k[1] & inflight), "reload of v%s while the previous load into it is in flight" % sorted(k[1])
+                assert not (k[2] & inflight), "load address taken from a register with a load in flight: " + body[i]
+                queue.append(("r", k[1]))
+            elif k[0] == "dma":
+                assert not (k[1] & inflight), "LDS-DMA address taken from a register with a load in flight: " + body[i]
+                queue.append(("d", set()))
+            elif k[0] == "barrier":
+                assert not any(q[0] == "d" for q in queue), "LDS-DMA piece still in flight at the barrier"
+            else:
+                assert not (k[1] & inflight), "load destination touched while the load is in flight: %s" % body[i]
+        assert queue == entered, "a pass of the loop does not leave the in-flight loads it was entered with"
     return len(body)
 
 

@@ -36,19 +36,19 @@ constexpr int X3_PX = (X3_ROWS + 2) * HALO_W;       // 612 halo pixels
 constexpr int X3_SINK = X3_PX * 32;                 // 19,584: each term image ends with a 512-B sink
 constexpr int X3_XT = X3_SINK + 512;                // 20,096 B per term image
 constexpr int X3_XB = 2 * X3_XT;                    // 40,192 B per input buffer (two term images)
-constexpr int X3_WOFF = 2 * X3_XB;                  // 120,576
+constexpr int X3_WOFF = 2 * X3_XB;                  // 80,384
 constexpr int X3_WSINK = H2_WH_BYTES;               // sink behind each weight buffer (1024 + 512 B)
 constexpr int X3_WB = H2_WH_BYTES + 2048;           // 20,480 B per weight buffer incl. its sink: TWO of them fit here (the
                                                     // three-term images of mode 3 leave no room), so a half-step ends
                                                     // with one barrier instead of the barrier / weight write / barrier
 constexpr int X3_BIAS = X3_WOFF + 2 * X3_WB;        // 121,344
-constexpr int X3_DESC = X3_BIAS + 5 * 32 * 4;       // 151,936
-constexpr int X3_LDS_BYTES = X3_DESC + 16 * 8;      // 152,064
+constexpr int X3_DESC = X3_BIAS + 5 * 32 * 4;       // 121,984
+constexpr int X3_LDS_BYTES = X3_DESC + 16 * 8;      // 122,112
 constexpr int X3_ROWB = HALO_W * 32;                // 1088
 constexpr int X3_XSLOTS = X3_PX * 4;                // 2448 float4 slots of an input half-tile
 constexpr int X3_XR = (X3_XSLOTS + X3_LT - 1) / X3_LT;     // 10
 constexpr int X3_WSLOTS = 9 * 64 * 2;               // 1152 float4 slots of an fp32 half-panel
-constexpr int X3_WR = (X3_WSLOTS + X3_LT - 1) / X3_LT;     // 5
+constexpr int X3_WR = (X3_WSLOTS + X3_LT - 1) / X3_LT;     // 5 LDS-DMA pieces per staging wave and half-step
 
 __device__ __forceinline__ void x3_split4(const f32x4& a, float s, u32x2& hi, u32x2& lo) { split2_f16x4(a, s, hi, lo); }   // xsd_split.h
 
@@ -135,17 +135,18 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
         // Staging slots of this thread: slot(r) = r*256 + lt -> halo pixel p = r*64 + (lt >> 2), channel quad q = lt & 3.
         // Everything per-lane about a slot is computed ahead of the loop and kept in registers: its LDS byte offset (fixed)
         // and its byte offset inside the input plane of the tile being prefetched (rebuilt when the tile changes).  A round
-        // of the loop is then: counted wait, 18-instruction split, three ds_write_b64, one buffer_load.
+        // of the loop is then: counted wait, 12-instruction split, two ds_write_b64, one buffer_load.
         //
         // Loads are BUFFER loads (128-bit descriptor in SGPRs + 32-bit lane offset): padding pixels, exhausted slots and the
         // rounds after the last half-step carry an offset / a descriptor length that fails the hardware range check, which
         // returns zeros without touching memory -- no zero page, no select, no 64-bit address arithmetic.
         // They are issued and waited for BY HAND (inline asm): hipcc's own bookkeeping puts one s_waitcnt vmcnt(0) in front
         // of the first conversion of a half-step, which halves the prefetch distance.  These waves execute no other
-        // vector-memory instruction, so the count is exact: every load is issued right after the conversion of the round
-        // whose register it refills, in the fixed order X0..X9, W0..W4; rounds are taken in pairs (four independent split
-        // chains for the in-order wave), and when a pair's data is needed exactly 13 younger loads exist (14 for the
-        // single last round) -- `s_waitcnt vmcnt(13)` keeps a whole half-step of loads in flight.  hipcc does not know these
+        // vector-memory instruction, so the count is exact: a pass issues the five LDS-DMA pieces of the next half-step's
+        // weights (below), then every input load right after the conversion of the round whose register it refills, in the
+        // fixed order X0..X9; rounds are taken in pairs (four independent split chains for the in-order wave), and when a
+        // pair's data is needed exactly 13 younger operations exist -- `s_waitcnt vmcnt(13)` keeps a whole half-step of
+        // input loads in flight.  hipcc does not know these
         // registers are written asynchronously: the load takes its destination as an in/out operand (the new value lands
         // where the consumed one was), the wait statement too, and tools/check_async_loads.py (run by tests/test_isa.py)
         // verifies in the generated code that nothing else in the loop touches them and that no other vmem op exists.
@@ -171,7 +172,6 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
             }
         };
         f32x4 pin[X3_XR] = {};
-        f32x4 pw[X3_WR] = {};
         // descriptors are read from LDS (per lane) and made scalar again: uniform values belong in SGPRs
         auto uniform64 = [&](unsigned long long v) {
             const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
@@ -200,7 +200,6 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
         auto asm_load4 = [&](f32x4& dst, int off, const i32x4& rs) {
             asm volatile("buffer_load_dwordx4 %[d], %[o], %[r], 0 offen" : [d] "+v"(dst) : [o] "v"(off), [r] "s"(rs) : "memory");
         };
-        auto asm_wait14 = [&](f32x4& v) { asm volatile("s_waitcnt vmcnt(14)" : "+v"(v) :: "memory"); };
         auto asm_wait13 = [&](f32x4& u, f32x4& v) { asm volatile("s_waitcnt vmcnt(13)" : "+v"(u), "+v"(v) :: "memory"); };
         auto load_x_round = [&](int r, const i32x4& rs) { asm_load4(pin[r], xoff[r], rs); };
         auto store_x_round = [&](int r, int xb) {   // xb: byte offset of the input buffer in LDS
@@ -212,27 +211,21 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + X3_XT) = lo;
         };
-        // (the lane offset of the weight loads is rebuilt from the lane id at each use: kept in a register across the loop
-        // it is spilled, and hipcc then waits vmcnt(0) for the scratch reload INSIDE the loop -- which drains the whole
-        // hand-counted prefetch; tools/check_async_loads.py rejects any such wait)
-        auto load_w_round = [&](int r, const i32x4& rs) {
+        // Weights by LDS-DMA: the pre-split half-panel is a lane-linear image, so `buffer_load_dwordx4 ... lds` copies it
+        // global -> LDS with no register, no ds_write and no address arithmetic (lane offset 16 * lane, the round and the
+        // wave in the scalar offset, the wave's 1-KiB destination in M0 -- written in the same statement, hipcc owns M0).
+        // In the last round only waves 0 and 1 have slots; the other two land in the sink behind the buffer.
+        const unsigned int lds0 = __builtin_amdgcn_readfirstlane((unsigned int)(unsigned long long)(__attribute__((address_space(3))) char*)smem);
+        auto dma_w_round = [&](int r, const i32x4& rs, int wb) {
             unsigned int all = ~0u;
             asm volatile("" : "+s"(all));
-            const int t = wid * 64 + (int)__builtin_amdgcn_mbcnt_hi(all, __builtin_amdgcn_mbcnt_lo(all, 0u));
-            asm_load4(pw[r], t * 16 + r * (X3_LT * 16), rs);
+            const int voff = 16 * (int)__builtin_amdgcn_mbcnt_hi(all, __builtin_amdgcn_mbcnt_lo(all, 0u));
+            const int soff = r * (X3_LT * 16) + wid * 1024;
+            const bool live = (r + 1) * X3_LT <= X3_WSLOTS || r * X3_LT + wid * 64 < X3_WSLOTS;     // wave-uniform
+            const unsigned int dst = lds0 + X3_WOFF + wb + (live ? soff : X3_WSINK + (wid & 1) * 1024);
+            asm volatile("s_mov_b32 m0, %[l]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[o], %[r], %[s] offen lds"
+                         :: [o] "v"(voff), [r] "s"(rs), [s] "s"(soff), [l] "s"(dst) : "memory");
         };
-        // the weight half-panel arrives pre-split (the pack step writes the two-term fp16 image [tap][h | l][lane][8 x f16],
-        // 18,432 B, exactly as it lies in LDS): a staging round is a 16-byte copy, no VALU
-        auto store_w_round = [&](int r, int wb) {   // wb: byte offset of the weight buffer in LDS
-            unsigned int all = ~0u;
-            asm volatile("" : "+s"(all));
-            const int t = wid * 64 + (int)__builtin_amdgcn_mbcnt_hi(all, __builtin_amdgcn_mbcnt_lo(all, 0u));
-            const int sl = r * X3_LT + t;
-            const bool live = (r + 1) * X3_LT <= X3_WSLOTS || sl < X3_WSLOTS;     // (compile-time true except in the last round)
-            char* d = w_lds + wb + (live ? sl * 16 : X3_WSINK + (t & 63) * 16);
-            *reinterpret_cast<f32x4*>(d) = pw[r];
-        };
-
         // prologue: half-step 0 into LDS, half-step 1 into the staging registers
         Cur cur = {0, 0, 0, 0};
         TileXY tcur = tile_of(0);
@@ -242,27 +235,23 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
 #pragma unroll
             for (int r = 0; r < X3_XR; ++r) load_x_round(r, b0);
 #pragma unroll
-            for (int r = 0; r < X3_WR; ++r) load_w_round(r, w0);
+            for (int r = 0; r < X3_WR; ++r) dma_w_round(r, w0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int r = 0; r < X3_XR; ++r) { asm volatile("" : "+v"(pin[r])); store_x_round(r, 0); }
-#pragma unroll
-            for (int r = 0; r < X3_WR; ++r) { asm volatile("" : "+v"(pw[r])); store_w_round(r, 0); }
         }
         Cur n1 = succ(cur);                 // same tile: a tile has at least two half-steps
         TileXY t1 = tcur;
         {
-            const i32x4 b1 = x_rsrc(n1, t1, items > 1), w1 = w_rsrc(n1, items > 1);
+            const i32x4 b1 = x_rsrc(n1, t1, items > 1);
 #pragma unroll
             for (int r = 0; r < X3_XR; ++r) load_x_round(r, b1);
-#pragma unroll
-            for (int r = 0; r < X3_WR; ++r) load_w_round(r, w1);
         }
         Cur n2 = succ(n1);
         TileXY t2 = t1;
         if (items > 2 && n2.k != n1.k) { t2 = tile_of(n2.k); tile_offsets(t2); }
         lds_barrier();                                                                     // (P)
-#ifdef XSD_DIAG   // staging-wave phase stamps, slots 8..12 (X rounds, W rounds, wait for barrier A, weight write, barrier B)
+#ifdef XSD_DIAG   // staging-wave phase stamps, slots 8..12 (X rounds, wait for the DMA pieces, barrier, -, descriptors + DMA issue)
         unsigned long long lst[5] = {0, 0, 0, 0, 0};
         unsigned long long lt0 = __builtin_readcyclecounter();
         const bool lstamp = P.dbg != nullptr;
@@ -275,8 +264,20 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
         for (int it = 0; it < items; ++it) {
             const bool more1 = (it + 1 < items), more2 = (it + 2 < items);
             X3_LTICK(4);
-            const i32x4 xrs = x_rsrc(n2, t2, more2), wrs = w_rsrc(n2, more2);
             const int xn = ((it + 1) & 1) * X3_XB;
+            const int wn = ((it + 1) & 1) * X3_WB;
+            // weights of half-step it+1 straight into the other weight buffer (free since the barrier that ended it-1): five
+            // DMA pieces, issued first, so that they are OLDER than this pass's ten input loads -- `vmcnt(10)` before the
+            // barrier retires them and leaves the input loads of half-step it+2 in flight; the pair waits below see
+            // 8 - 2k older input loads + 5 pieces + 2k refills = 13 younger operations, as in the register scheme
+            {
+                const i32x4 wrs1 = w_rsrc(n1, more1);
+                if (!(abl & 4)) {
+#pragma unroll
+                    for (int r = 0; r < X3_WR; ++r) dma_w_round(r, wrs1, wn);
+                }
+            }
+            const i32x4 xrs = x_rsrc(n2, t2, more2);
             // input of half-step it+1: registers -> the other buffer; then refill each register with half-step it+2
 #pragma unroll
             for (int r = 0; r < X3_XR; r += 2) {     // two rounds at a time: four independent split chains in flight
@@ -287,21 +288,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
                 __builtin_amdgcn_sched_barrier(0);   // a pair at a time, in order (the wait counts depend on it)
             }
             X3_LTICK(0);
-            // weights of half-step it+1 -> the other weight buffer, the same way
-            const int wn = ((it + 1) & 1) * X3_WB;
-#pragma unroll
-            for (int r = 0; r + 1 < X3_WR; r += 2) {
-                if (!(abl & 4)) asm_wait13(pw[r], pw[r + 1]);
-                store_w_round(r, wn);
-                store_w_round(r + 1, wn);
-                if (!(abl & 4)) { load_w_round(r, wrs); load_w_round(r + 1, wrs); }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            static_assert(X3_XR % 2 == 0 && X3_WR % 2 == 1, "pairing of the staging rounds");
-            if (!(abl & 4)) asm_wait14(pw[X3_WR - 1]);
-            store_w_round(X3_WR - 1, wn);
-            if (!(abl & 4)) load_w_round(X3_WR - 1, wrs);
-            __builtin_amdgcn_sched_barrier(0);
+            if (!(abl & 4)) asm volatile("s_waitcnt vmcnt(%[n])" :: [n] "n"(X3_XR) : "memory");   // the DMA pieces have landed
             X3_LTICK(1);
             lds_barrier();                                                                 // end of half-step `it`
             X3_LTICK(2);
