@@ -132,6 +132,9 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
 
     if (loader) {
         // ============================ staging waves ============================
+#ifdef X3_LPRIO
+        __builtin_amdgcn_s_setprio(X3_LPRIO);
+#endif
         // Staging slots of this thread: slot(r) = r*256 + lt -> halo pixel p = r*64 + (lt >> 2), channel quad q = lt & 3.
         // Everything per-lane about a slot is computed ahead of the loop and kept in registers: its LDS byte offset (fixed)
         // and its byte offset inside the input plane of the tile being prefetched (rebuilt when the tile changes).  A round
@@ -307,7 +310,10 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
     }
 
     // ============================== MFMA waves ==============================
-    __builtin_amdgcn_s_setprio(2);   // the MFMA waves are the critical path, the staging waves have ~30 % slack (A/B on one device: -0.9 %)
+#ifndef X3_MPRIO
+#define X3_MPRIO 2
+#endif
+    __builtin_amdgcn_s_setprio(X3_MPRIO);   // the MFMA waves are the critical path, the staging waves have ~30 % slack (A/B on one device: -0.9 %)
     f32x16 acc[2], accx[2];
     auto init_acc = [&](int j) {
         int hh = lane;                    // rebuilt from the lane id: held across the loop it is spilled

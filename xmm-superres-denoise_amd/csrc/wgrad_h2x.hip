@@ -140,6 +140,9 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
 
     if (loader) {
         // ============================ staging waves ============================
+#ifdef V3_LPRIO
+        __builtin_amdgcn_s_setprio(V3_LPRIO);
+#endif
         const int lt = tid;
         const PlaneIn xp = P.x[j];
         const PlaneIn gp = P.g[n];
@@ -293,6 +296,9 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
         // tiles past the end were staged as zeros (empty descriptors): bsum took 0 from them; tile 0 and 1 were counted once each
     } else {
         // ============================== MFMA waves ==============================
+#ifdef V3_MPRIO
+        __builtin_amdgcn_s_setprio(V3_MPRIO);
+#endif
         const int wv = wid - V3_LWAVES;        // which of the 27 units (4,4,4,3,3,3,3,3 per wave); u / 9 = product (0 Xh*Gh, 1 Xh*Gl, 2 Xl*Gh), u % 9 = tap
 #pragma unroll
         for (int k = 0; k < NU; ++k)
