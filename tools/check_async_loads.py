@@ -48,7 +48,10 @@ def check(asm_text, NLOADS=15):
         start = min(members)
         end = max(j for j, l in enumerate(lines) if re.search(r"s_c?branch\w*\s+(\S+)", l) and l.split()[-1] in labels)
         loops.append((start, end))
-    cand = [(a, b) for a, b in loops if sum("buffer_load_dwordx4" in l for l in lines[a:b]) == NLOADS]
+    # (a loop whose vector-memory operations are all LDS-DMA pieces -- the H2-input variant of the conv -- has no register
+    # destination to protect and drains with vmcnt(0): not a candidate)
+    cand = [(a, b) for a, b in loops if sum("buffer_load_dwordx4" in l for l in lines[a:b]) == NLOADS
+            and any("buffer_load_dwordx4" in l and not l.split(";")[0].rstrip().endswith(" lds") for l in lines[a:b])]
     assert len(cand) == 1, "staging loop not found (loops with %d buffer loads: %d)" % (NLOADS, len(cand))
     a, b = cand[0]
     body = [l.split(";")[0].strip() for l in lines[a:b + 1]]

@@ -437,6 +437,32 @@ __global__ void plane_amax_kernel(PlaneIn v, int B, int H, int W, float* slot)
     }
     atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(m));
 }
+#ifdef XSD_EXP_H2
+// math mode 4, experiment XSD_H2: fp32 plane -> "H2" plane, the two fp16 terms of xsd_split.h stored as
+// [pixel][channel half s2][term h | l][16 x f16] (the same 128 B per pixel), scaled with the plane's own max |x|; the scale goes to
+// `hscale` for the consumers (conv3x3_h2x_kernel<true> fetches such planes by LDS-DMA, no conversion in the staging waves).
+__global__ void plane_to_h2_kernel(PlaneIn v, int B, int H, int W, const float* amax, unsigned int* dst, float* hscale)
+{
+    float inv;
+    const float sc = scale_for_amax(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *amax))), inv);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *hscale = sc;
+    const long long total = (long long)B * H * W * 8;        // (pixel, channel quad)
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(g & 7);
+        long long pix = g >> 3;
+        const long long opix = pix;
+        const int x = (int)(pix % W); pix /= W;
+        const int y = (int)(pix % H);
+        const int b = (int)(pix / H);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(v.p + (long long)b * v.bs + (long long)y * v.rs + (long long)x * v.ps + q * 4);
+        split_u32x2 hi, lo;
+        split2_f16x4(t, sc, hi, lo);
+        unsigned int* d = dst + opix * 32 + (q >> 2) * 16 + (q & 3) * 2;      // 32 words per pixel; half s2 = 16 words: h 8 words, l 8 words
+        *reinterpret_cast<split_u32x2*>(d) = hi;
+        *reinterpret_cast<split_u32x2*>(d + 8) = lo;
+    }
+}
+#endif
 __global__ void buffer_amax_kernel(const float* v, long long n, float* slot)
 {
     float m = 0.f;
@@ -701,6 +727,13 @@ hipError_t launch_plane_amax(const PlaneIn& v, int B, int H, int W, float* slot,
     hipLaunchKernelGGL(plane_amax_kernel, dim3(grid_for((long long)B * H * W * 8, 256)), dim3(256), 0, s, v, B, H, W, slot);
     return hipGetLastError();
 }
+#ifdef XSD_EXP_H2
+hipError_t launch_plane_to_h2(const PlaneIn& v, int B, int H, int W, const float* amax, void* dst, float* hscale, hipStream_t s)
+{
+    hipLaunchKernelGGL(plane_to_h2_kernel, dim3(grid_for((long long)B * H * W * 8, 256)), dim3(256), 0, s, v, B, H, W, amax, reinterpret_cast<unsigned int*>(dst), hscale);
+    return hipGetLastError();
+}
+#endif
 hipError_t launch_buffer_amax(const float* v, long long n, float* slot, hipStream_t s)
 {
     hipLaunchKernelGGL(buffer_amax_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, s, v, n, slot);

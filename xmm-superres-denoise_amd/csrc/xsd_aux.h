@@ -49,6 +49,7 @@ hipError_t launch_plane_convert(const float* in, float* out, long long npix, int
 hipError_t launch_plane_amax(const PlaneIn& v, int B, int H, int W, float* slot, hipStream_t s);   // math mode 4
 hipError_t launch_buffer_amax(const float* v, long long n, float* slot, hipStream_t s);
 hipError_t launch_split_panels_f16(const float* src, void* dst, long long nfloats, const float* amax, hipStream_t s);
+hipError_t launch_plane_to_h2(const PlaneIn& v, int B, int H, int W, const float* amax, void* dst, float* hscale, hipStream_t s);   // experiment XSD_H2
 hipError_t launch_conv3x3_h2x(const ConvParams& p, hipStream_t stream);
 hipError_t launch_conv3x3_p16(const ConvParams& p, hipStream_t stream);
 hipError_t launch_wgrad_p16(const WgradParams& p, hipStream_t stream);

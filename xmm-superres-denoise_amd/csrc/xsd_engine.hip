@@ -82,6 +82,7 @@ struct xsd_engine {
     unsigned short* pk_bwd_s = nullptr;
     int chunk = 0;             // diagnostic library only (env XSD_CHUNK): images per dense-block sweep (0 = whole batch)
     int ablate = 0;            // diagnostic library only (env XSD_ABLATE): ablation knobs of the kernels
+    int h2 = 0;                // experiment builds only (-DXSD_EXP_H2, env XSD_H2=1): pre-split copies of the forward planes, fetched by LDS-DMA
     int math = 4;              // include/xsd.h: xsd_set_math (default: f16x3, the faster of the two fp32-class split modes)
     float* pk_edge = nullptr; // first_fwd, first_bwd, last_fwd, last_bwd (288 each)
     float* pk_sbias = nullptr;
@@ -212,6 +213,27 @@ struct Builder {
     // a plane_amax launch in front of the first consumer); a view dies when its buffer is handed out again
     typedef std::tuple<uintptr_t, int, int> ViewKey;
     std::map<ViewKey, float*> amax_valid;
+    // experiment XSD_H2: pre-split copy (and the slot of its scale) of a level-0 plane in standard layout
+    std::map<const float*, std::pair<void*, float*>> h2_of;
+    void make_h2(std::vector<Launch>& F, float* plane)
+    {
+#ifdef XSD_EXP_H2
+        if (!e->h2 || e->math != 4) return;
+        std::vector<Launch> pre;
+        const PlaneIn v = std_in(plane, 0);
+        float* am = slot_of(v, H, W, pre);
+        void* dst = alloc(0);
+        float* hs = new_slot();
+        h2_of[plane] = std::make_pair(dst, hs);
+        const int Bv = B, Hv = H, Wv = W;
+        F.push_back([v, Bv, Hv, Wv, am, dst, hs, pre](hipStream_t s) mutable {
+            for (auto& f : pre) { hipError_t err = f(s); if (err != hipSuccess) return err; }
+            return launch_plane_to_h2(v, Bv, Hv, Wv, am, dst, hs, s);
+        });
+#else
+        (void)F; (void)plane;
+#endif
+    }
     Builder(xsd_engine* e_, int B_, int H_, int W_, bool train_, uintptr_t base_)
         : e(e_), B(B_), H(H_), W(W_), train(train_), base(base_), freelist(8) {}
 
@@ -251,6 +273,7 @@ struct Builder {
         if (!freelist[level].empty()) { off = freelist[level].back(); freelist[level].pop_back(); }
         else { off = top; top += plane_bytes(level); if (top > peak) peak = top; }
         if (e->math == 4) invalidate_range(base + off, plane_bytes(level));
+        h2_of.erase(reinterpret_cast<const float*>(base + off));
         return reinterpret_cast<float*>(base + off);
     }
     float* alloc1(int level) // 1-channel image
@@ -345,6 +368,11 @@ struct Builder {
                 amax_valid[ViewKey(reinterpret_cast<uintptr_t>(o.p), o.rs, o.ps)] = o.amax;
             }
         }
+        if (e->h2 && e->math == 4 && p.n_out == 1) {      // experiment XSD_H2: every input has a pre-split copy -> LDS-DMA staging
+            bool all = true;
+            for (int i = 0; i < p.n_in; ++i) all = all && h2_of.count(p.in[i].p) && p.in[i].ps == 32 && p.in[i].rs == p.W * 32 && p.H == H && p.W == W && p.B == B;
+            if (all) for (int i = 0; i < p.n_in; ++i) { p.in_h2[i] = h2_of[p.in[i].p].first; p.hscale[i] = h2_of[p.in[i].p].second; }
+        }
         return [eng, p, pre, bias_from_params, bias_off, flop, bytes](hipStream_t s) mutable {
             if (bias_from_params) p.bias = eng->params + bias_off;
             p.dbg = eng->dbg;
@@ -415,6 +443,7 @@ struct Builder {
             const long long boff = e->first_b;
             F.push_back([eng, p, boff](hipStream_t s) mutable { p.s = eng->b_x; p.bias = eng->params + boff; return launch_edge_expand(p, s); });
         }
+        make_h2(F, fea);
         float* cur = fea;
         for (int i = 0; i < blocks; ++i) {
             rin[i] = cur;
@@ -447,8 +476,10 @@ struct Builder {
                 // (6 x 33.5 MB per 512^2 image) stay in the Infinity Cache between conv_k and conv_{k+1..5}.
                 const int cb = (e->chunk > 0 && e->chunk < B) ? e->chunk : B;
                 for (int b0 = 0; b0 < B; b0 += cb)
-                    for (int c = 0; c < 5; ++c)
+                    for (int c = 0; c < 5; ++c) {
                         F.push_back(conv_launch(slice(rp[c], b0, std::min(cb, B - b0)), true, e->rdb[(i * 3 + r) * 5 + c].b_off));
+                        if (cb == B) make_h2(F, rp[c].out[0].p);
+                    }
                 for (int k = 0; k < 4; ++k) release(a.xs[k], 0);
                 if (r > 0) release(a.xin, 0);
                 cur = a.out;
@@ -678,6 +709,9 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
 #ifdef XSD_DIAG   // the diagnostic library variant (make diag, selected with XSD_LIB) is the only build that reads these
     if (const char* m = getenv("XSD_ABLATE")) e->ablate = atoi(m);
     if (const char* m = getenv("XSD_CHUNK")) e->chunk = atoi(m);
+#endif
+#ifdef XSD_EXP_H2
+    if (const char* m = getenv("XSD_H2")) e->h2 = atoi(m);
 #endif
     if (const char* m = getenv("XSD_MATH")) e->math = (strcmp(m, "f16x3") == 0 || strcmp(m, "4") == 0) ? 4 : (strcmp(m, "bf16x6") == 0 || strcmp(m, "3") == 0) ? 3 : (strcmp(m, "bf16x3_p16") == 0 || strcmp(m, "2") == 0) ? 2 : (strcmp(m, "bf16x3") == 0 || strcmp(m, "1") == 0) ? 1 : 0;
     const int blocks = cfg->num_res_blocks, nup = cfg->kind == XSD_KIND_SR ? cfg->num_upsample : 0;

@@ -77,6 +77,10 @@ struct ConvParams {
     // the producers, read at kernel start); the kernel scales both operands by powers of two into the fp16 range
     const float* amax_in[5];
     const float* amax_w;
+    // experiment XSD_H2: pre-split copies of the input planes ([pixel][s2][h | l][16 x f16], standard layout) and the scale
+    // each was split with; when every input has one the kernel fetches them by LDS-DMA
+    const void* in_h2[5];
+    const float* hscale[5];
     OutDesc out[5];
 };
 
