@@ -78,8 +78,6 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
     const bool loader = wid < X3_LWAVES;               // wave-uniform role
     const int lt = tid;                                // staging thread index 0..255 (staging waves only)
     const int wv = wid - X3_LWAVES;                    // MFMA wave index 0..7 -> tile rows 2wv, 2wv+1
-    const int h = lane >> 5;
-    const int l31 = lane & 31;
 
     const int tilesY = (P.H + X3_ROWS - 1) / X3_ROWS;
     const int ntiles = P.B * tilesY * P.tilesX;
@@ -530,10 +528,16 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
 
     // Epilogue over fp32 planes (straight-line operand variants; lanes outside the image read the zero page and write a
     // trash page): each lane owns one pixel and 16 channels as four float4 groups.
-    float* const trash = const_cast<float*>(zero) + 64 + 4 * h;
     auto epilogue_v = [&](const OutDesc& o, const TileXY& T, auto has_acc, auto has_e1, auto has_e2, auto has_e3, auto has_mask, auto generic) {
         float* dst = o.p + (long long)T.b * o.bs;
         const long long sb = (long long)T.b * P.std_bs;
+        // lane coordinates rebuilt from the lane id here (held across the K-loop they are spilled, and a scratch reload in the
+        // epilogue is a full memory round trip -- ~4 us under this kernel's load -- with the matrix pipe idle: -1.8 %)
+        unsigned int all = ~0u;
+        asm volatile("" : "+s"(all));
+        const int ln = (int)__builtin_amdgcn_mbcnt_hi(all, __builtin_amdgcn_mbcnt_lo(all, 0u));
+        const int h = ln >> 5, l31 = ln & 31;
+        float* const trash = const_cast<float*>(zero) + 64 + 4 * h;
         const int x = T.x0 + l31;
         const float s1 = (decltype(generic)::value && !o.e1) ? 0.f : o.s1, s2v = (decltype(generic)::value && !o.e2) ? 0.f : o.s2;
         const float s3 = (decltype(generic)::value && !o.e3) ? 0.f : o.s3, msl = (decltype(generic)::value && !o.mask) ? 1.f : o.mslope;
