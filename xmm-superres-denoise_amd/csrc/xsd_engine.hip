@@ -432,6 +432,7 @@ struct Builder {
 
         struct RdbAct { float* xin; float* xs[4]; float* out; unsigned short* xb[4]; };
         const bool use_bits = train && e->math == 2; // compact lrelu' masks (conv3x3_p16 epilogue)
+        const bool rdb_bits = train && (e->math == 2 || e->math == 4);   // ... of the dense blocks' activations (conv3x3_h2x epilogue too)
         std::vector<RdbAct> acts(blocks * 3);
         std::vector<float*> rin(blocks + 1);
 
@@ -462,7 +463,7 @@ struct Builder {
                     std_out(p.out[0], o, 0);
                     if (c < 4) {                                            // rrdb_blocks.py:38-52
                         p.out[0].slope = 0.2f; a.xs[c] = o;
-                        a.xb[c] = use_bits ? reinterpret_cast<unsigned short*>(alloc1(0)) : nullptr;
+                        a.xb[c] = rdb_bits ? reinterpret_cast<unsigned short*>(alloc1(0)) : nullptr;
                         p.out[0].bits_out = a.xb[c];
                     }
                     else {
