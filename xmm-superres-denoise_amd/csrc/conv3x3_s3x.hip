@@ -393,7 +393,8 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
 
     // Epilogue over fp32 planes (straight-line operand variants; lanes outside the image read the zero page and write a
     // trash page): each lane owns one pixel and 16 channels as four float4 groups.
-    auto epilogue_v = [&](const OutDesc& o, const TileXY& T, auto has_acc, auto has_e1, auto has_e2, auto has_e3, auto has_mask, auto generic) {
+    auto epilogue_v = [&](const OutDesc& o, const TileXY& T, auto has_acc, auto has_e1, auto has_e2, auto has_e3, auto has_mask, auto generic, auto has_bits, auto has_bout) {
+        // has_bits / has_bout: compact lrelu' masks, one 16-bit word per lane and row (conv3x3_h2x.hip)
         float* dst = o.p + (long long)T.b * o.bs;
         const long long sb = (long long)T.b * P.std_bs;
         // lane coordinates rebuilt from the lane id here: held across the K-loop they are spilled, and a scratch reload in the
@@ -417,13 +418,16 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
             const float *p1 = opnd(o.e1), *p2 = opnd(o.e2), *p3 = opnd(o.e3), *pm = opnd(o.mask);
             const float* pa = (valid && o.accumulate) ? dp : zero;
             f32x4 va[4], v1[4], v2[4], v3[4], vm[4];
+            const int widx = (((int)T.b * P.H + y) * P.W + x) * 2 + h;     // (pixel, lane half) -> 16-bit word (B*H*W*2 < 2^31)
+            unsigned int mbits = 0, obits = 0;
+            if constexpr (decltype(has_bits)::value) mbits = o.bits_in[valid ? widx : 0];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if constexpr (decltype(has_acc)::value) va[q] = x3_gload4(pa + 8 * q);
                 if constexpr (decltype(has_e1)::value) v1[q] = x3_gload4(p1 + 8 * q);
                 if constexpr (decltype(has_e2)::value) v2[q] = x3_gload4(p2 + 8 * q);
                 if constexpr (decltype(has_e3)::value) v3[q] = x3_gload4(p3 + 8 * q);
-                if constexpr (decltype(has_mask)::value) vm[q] = x3_gload4(pm + 8 * q);
+                if constexpr (decltype(has_mask)::value && !decltype(has_bits)::value) vm[q] = x3_gload4(pm + 8 * q);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -437,26 +441,36 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
                 if constexpr (decltype(has_e3)::value) v += s3 * v3[q];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = v[t] > 0.f ? v[t] : v[t] * o.slope;
-                if constexpr (decltype(has_mask)::value) {
+                if constexpr (decltype(has_bits)::value) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = ((mbits >> (4 * q + t)) & 1u) ? v[t] : v[t] * msl;
+                } else if constexpr (decltype(has_mask)::value) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) v[t] = vm[q][t] > 0.f ? v[t] : v[t] * msl;
+                }
+                if constexpr (decltype(has_bout)::value) {      // this plane's own lrelu' mask for the backward pass
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) obits |= (v[t] > 0.f ? 1u : 0u) << (4 * q + t);
                 }
                 pend[4 * r + q] = v;
             }
             pend_dp[r] = dp;
+            if constexpr (decltype(has_bout)::value) { if (valid) o.bits_out[widx] = (unsigned short)obits; }
         }
     };
     auto epilogue = [&](int j, const TileXY& T) {
         const OutDesc o = P.out[j];
         using Y = std::true_type; using N = std::false_type;
         const int kind = (o.accumulate ? 1 : 0) | (o.e1 ? 2 : 0) | (o.e2 ? 4 : 0) | (o.e3 ? 8 : 0) | (o.mask ? 16 : 0);
-        switch (kind) {
-        case 0: epilogue_v(o, T, N{}, N{}, N{}, N{}, N{}, N{}); break;
-        case 2: epilogue_v(o, T, N{}, Y{}, N{}, N{}, N{}, N{}); break;
-        case 6: epilogue_v(o, T, N{}, Y{}, Y{}, N{}, N{}, N{}); break;
-        case 14: epilogue_v(o, T, N{}, Y{}, Y{}, Y{}, N{}, N{}); break;
-        case 16: epilogue_v(o, T, N{}, N{}, N{}, N{}, Y{}, N{}); break;
-        default: epilogue_v(o, T, Y{}, Y{}, Y{}, Y{}, Y{}, Y{}); break;   // any other combination (none in the engine's plans)
+        switch (kind | ((o.mask && o.bits_in) ? 32 : 0) | (o.bits_out ? 64 : 0)) {
+        case 0: epilogue_v(o, T, N{}, N{}, N{}, N{}, N{}, N{}, N{}, N{}); break;
+        case 64: epilogue_v(o, T, N{}, N{}, N{}, N{}, N{}, N{}, N{}, Y{}); break;
+        case 2: epilogue_v(o, T, N{}, Y{}, N{}, N{}, N{}, N{}, N{}, N{}); break;
+        case 6: epilogue_v(o, T, N{}, Y{}, Y{}, N{}, N{}, N{}, N{}, N{}); break;
+        case 14: epilogue_v(o, T, N{}, Y{}, Y{}, Y{}, N{}, N{}, N{}, N{}); break;
+        case 16: epilogue_v(o, T, N{}, N{}, N{}, N{}, Y{}, N{}, N{}, N{}); break;
+        case 48: epilogue_v(o, T, N{}, N{}, N{}, N{}, Y{}, N{}, Y{}, N{}); break;
+        default: epilogue_v(o, T, Y{}, Y{}, Y{}, Y{}, Y{}, Y{}, N{}, N{}); break;   // any other combination (none in the engine's plans)
         }
         // every load of the epilogue (operands, register reloads) has landed before the MFMA walk starts: its deferred
         // stores then need no vector-memory waits (hipcc would otherwise put `vmcnt(1)` in front of each, i.e. wait for

@@ -133,14 +133,17 @@ static void take_conv(long long& off, int cout, int cin, long long& w, long long
 // bf16x6 conv: the default is the role-split kernel (8 MFMA + 4 staging waves, conv3x3_s3x.hip); the build flag
 // XSD_CONV_UNIFIED (A/B builds, `make unified`) selects the 8-wave kernel in which every wave stages and multiplies
 // (conv3x3_s3.hip).  In the diagnostic library ablate bit 20 picks the other one.
-static hipError_t launch_conv_bf16x6(int ablate, const ConvParams& p, hipStream_t s)
+static bool conv_bf16x6_unified(int ablate)
 {
 #ifdef XSD_CONV_UNIFIED
-    const bool unified = !(ablate & (1 << 20));
+    return !(ablate & (1 << 20));
 #else
-    const bool unified = (ablate & (1 << 20)) != 0;
+    return (ablate & (1 << 20)) != 0;
 #endif
-    return unified ? launch_conv3x3_s3(p, s) : launch_conv3x3_s3x(p, s);
+}
+static hipError_t launch_conv_bf16x6(int ablate, const ConvParams& p, hipStream_t s)
+{
+    return conv_bf16x6_unified(ablate) ? launch_conv3x3_s3(p, s) : launch_conv3x3_s3x(p, s);
 }
 
 // bf16x6 weight gradient, same switch: role-split kernel (one workgroup per CU, `nparts` partial sums) or the unified one
@@ -432,7 +435,7 @@ struct Builder {
 
         struct RdbAct { float* xin; float* xs[4]; float* out; unsigned short* xb[4]; };
         const bool use_bits = train && e->math == 2; // compact lrelu' masks (conv3x3_p16 epilogue)
-        const bool rdb_bits = train && (e->math == 2 || e->math == 4);   // ... of the dense blocks' activations (conv3x3_h2x epilogue too)
+        const bool rdb_bits = train && (e->math == 2 || e->math == 4 || (e->math == 3 && !conv_bf16x6_unified(e->ablate)));   // ... of the dense blocks' activations (role-split conv epilogues too)
         std::vector<RdbAct> acts(blocks * 3);
         std::vector<float*> rin(blocks + 1);
 
