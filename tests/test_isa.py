@@ -47,3 +47,29 @@ def test_checker_rejects_broken_loops():
         chk.check(loop(rounds(extra="global_load_dword v101, v[102:103], off")))   # foreign vector-memory instruction
     with pytest.raises(AssertionError):
         chk.check(loop(rounds(wait="s_waitcnt vmcnt(13)")))              # wrong count for single rounds
+
+
+def test_checker_handles_lds_dma_pieces():
+    """LDS-DMA pieces (no register destination) share the vmcnt queue: they must have landed at the barrier, and a wait that
+    retires them early (or a register load's data too early) is rejected"""
+    import check_async_loads as chk
+
+    NX, ND = 10, 5
+
+    def loop(final_wait):
+        pro = ["\tbuffer_load_dwordx4 v[%d:%d], v90, s[0:3], 0 offen" % (4 * k, 4 * k + 3) for k in range(NX)]
+        pro = pro + ["\ts_waitcnt vmcnt(0)"] + pro
+        body = ["\tbuffer_load_dwordx4 v91, s[4:7], s8 offen lds" for _ in range(ND)]
+        for k in range(0, NX, 2):
+            body += ["\ts_waitcnt vmcnt(13)", "\tv_mov_b32_e32 v100, v%d" % (4 * k), "\tv_mov_b32_e32 v101, v%d" % (4 * k + 4),
+                     "\tbuffer_load_dwordx4 v[%d:%d], v90, s[0:3], 0 offen" % (4 * k, 4 * k + 3),
+                     "\tbuffer_load_dwordx4 v[%d:%d], v90, s[0:3], 0 offen" % (4 * k + 4, 4 * k + 7)]
+        body += ["\t" + final_wait, "\ts_barrier"] if final_wait else ["\ts_barrier"]
+        return "\n".join(pro + [".LBB0_1:                ; =>This Inner Loop Header: Depth=1"] + body + ["\ts_cbranch_scc1 .LBB0_1", "\ts_endpgm"])
+
+    assert chk.check(loop("s_waitcnt vmcnt(10)"), NX + ND) > 0
+    with pytest.raises(AssertionError):
+        chk.check(loop(None), NX + ND)                          # pieces still in flight at the barrier
+    with pytest.raises(AssertionError):
+        chk.check(loop("s_waitcnt vmcnt(8)"), NX + ND)          # retires two register loads nobody consumes before the next wait
+
