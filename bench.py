@@ -5,19 +5,19 @@ A "step" = one pass of the hot path over one batch of synthetic tiles (x ~ U[0,1
 reference-default weight init under torch.manual_seed(0)):
     weight repack -> forward (activations kept) -> mean-L1 loss -> backward (input + weight gradients)
     -> [RCCL all-reduce of the flat gradient, overlapped with backward, when N > 1] -> fused Adam.
-Default workload at N=1: BASELINE configs[2] "XMM-DeNoise train step, batch 32, 1 MI355X, fwd+bwd HIP kernels".
-At N>1 each rank keeps 16 tiles (configs[3]/[4]: 64 over 4, 128 over 8), weak scaling, one process per GPU.
+Workload: BASELINE configs[2] "XMM-DeNoise train step, batch 32, 1 MI355X, fwd+bwd HIP kernels".  The per-GPU batch is 32 at
+EVERY N (weak scaling of configs[2]: the N = 1 line and the N > 1 lines run the same per-GPU work, so a scaling efficiency
+computed from them is like-for-like); `--batch 16` gives the per-GPU share of configs[3]/[4] (64 over 4, 128 over 8).
 Other workloads (parity-test configs, not bench lines): --workload sr_fwd (configs[1]), sr_train, dn_fwd.
 
-The headline `value` is measured in an fp32-class math mode over the full --steps/--warmup.  Default `--math f16x3`: every
-operand tensor scaled by a power of two from its max |x| and split into two fp16 terms (22-23 of fp32's 24 significant
-bits), three fp16 MFMA products per fp32 product (forward, input-gradient and weight-gradient kernels), MFMA
-single-rounding fp32 accumulation, fp32 planes.  tests/test_hip_precision.py measures it against float64 on
-the goldens, a 512 x 512 four-block net and the backward pass: forward below torch's fp32 path and below this engine's
-exact-fp32 MFMA mode, backward never above the exact-fp32 MFMA mode (an fp32 fma chain) and within 2x of torch's CPU
-kernel.  `--math bf16x6` is the strict fp32-class mode (exact three-term bf16 split, six products: below BOTH yard-sticks
-everywhere, forward and backward) and rides along as the labelled `extra` leg; `--math fp32` is the exact fp32 MFMA mode.
-The 16-bit-significand modes (`bf16x3`, `bf16x3_p16`) are not fp32-class.
+Math modes (include/xsd.h: xsd_set_math), all with fp32 planes and fp32 MFMA accumulation:
+  f16x3  (default, the headline `value`): operands as two-term fp16 splits of power-of-two-scaled tensors, 22-23 significant
+         bits per operand (fp32 has 24), three fp16 MFMA products per multiply.  Measured against float64
+         (tests/test_hip_precision.py; log under profiles/): forward error below torch's fp32 CPU path; backward within 2x of
+         it and at the level of an exact fp32 fma chain.  `dtype` says exactly that, not "f32".
+  bf16x6 (strict; the `extra` leg, timed over the same --steps/--warmup with its own roofline block): exact three-term bf16
+         split, six products: error below torch fp32 everywhere, forward and backward.
+  fp32   exact fp32 MFMA.
 
 `python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself (one child process per GPU via
 torch.distributed.run; the parent never touches the GPU) and relays rank 0's JSON line; under an external torchrun it
@@ -25,8 +25,9 @@ runs as a rank.  XSD_DIST_BACKEND=gloo rehearses the multi-rank path on a box wi
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     : the dominant kernel's algorithmic FLOP (or bytes) / its average HIP-event launch time inside the timed
-                 region against the peak that binds the mode (fp32: 157.3 TFLOP/s fp32 MFMA; MI355X_MICROARCH.md), and
-  cpu_baseline : the same train step (B=1) through oracle/oracle.py's torch restatement on the host cores.
+                 region against the peak that binds the mode (MI355X_MICROARCH.md), and
+  cpu_baseline : the same train step (B=1) through oracle/oracle.py's torch restatement on the host cores (1 warm-up step,
+                 then best of 3; every sample recorded).
 """
 import argparse
 import json
@@ -62,9 +63,10 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(kind: str, train: bool):
-    """Reference op graph on the host CPU (torch restatement, pinned to the reference by tests/test_oracle_pinned.py):
-    one B=1 512x512 step, all host cores."""
+def cpu_baseline(kind: str, train: bool, repeats: int = 3):
+    """Reference op graph on the host CPU (torch restatement, pinned to the reference by tests/test_oracle_pinned.py): B=1
+    512x512 steps on all host cores -- one untimed warm-up step at full size (thread pool, oneDNN primitives, allocator),
+    then `repeats` timed steps; the best is `value`, every sample is recorded."""
     from oracle import oracle
     from xmm_superres_denoise.models import GeneratorRRDB_DN, GeneratorRRDB_SR
     cores = host_cores()
@@ -77,55 +79,98 @@ def cpu_baseline(kind: str, train: bool):
     s = 2 if kind == "sr" else 1
     t = torch.rand((1, 1, TILE * s, TILE * s), generator=torch.Generator().manual_seed(1))
     opt = torch.optim.Adam(list(state.values()), lr=1e-4, betas=(0.9, 0.999)) if train else None
-    # warm-up on a small tile (thread pool / oneDNN primitive creation), then ONE timed full-size step
-    with torch.set_grad_enabled(train):
-        oracle.torch_forward(kind, 32, 4, state, x[..., :64, :64])
-    t0 = time.perf_counter()
-    if train:
-        y = oracle.torch_forward(kind, 32, 4, state, x)
-        loss = torch.nn.functional.l1_loss(y, t)
-        loss.backward()
-        opt.step()
-    else:
-        with torch.no_grad():
-            oracle.torch_forward(kind, 32, 4, state, x)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"1 {'train step (fwd+L1+bwd+Adam)' if train else 'forward'} of 1 tile 1x{TILE}x{TILE}, torch-CPU "
-                      f"restatement of the reference graph (oracle/oracle.py:torch_forward), {dt:.1f} s"}
+
+    def one_step():
+        t0 = time.perf_counter()
+        if train:
+            opt.zero_grad(set_to_none=True)
+            y = oracle.torch_forward(kind, 32, 4, state, x)
+            loss = torch.nn.functional.l1_loss(y, t)
+            loss.backward()
+            opt.step()
+        else:
+            with torch.no_grad():
+                oracle.torch_forward(kind, 32, 4, state, x)
+        return time.perf_counter() - t0
+
+    warm = one_step()
+    samples = [one_step() for _ in range(repeats)]
+    best = min(samples)
+    return {"value": 1.0 / best, "unit": "tiles/s", "cores": cores, "kind": "port",
+            "samples_s": [round(v, 3) for v in samples], "warmup_s": round(warm, 3),
+            "sample": f"{'train step (fwd+L1+bwd+Adam)' if train else 'forward'} of 1 tile 1x{TILE}x{TILE}, torch-CPU restatement of the "
+                      f"reference graph (oracle/oracle.py:torch_forward): 1 warm-up + best of {repeats} ({best:.1f} s)"}
 
 
-BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md); bf16x3 spends 3 MFMAs per fp32 product
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0
 
 
 def pmc_traffic(math: str, batch: int, klass: str):
-    """HBM bytes per launch from the committed PMC passes (tools/traffic.sh -> profiles/rNN_traffic_<math>.json, newest round first),
-    valid only for the workload/batch they were collected on; None otherwise."""
-    for rnd in ("r02", "r01"):
-        f = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{math}.json")
+    """HBM bytes per launch from the committed PMC passes (tools/traffic.sh -> profiles/rNN_traffic_<math>.json, newest round
+    first), valid only for the workload/batch they were collected on.  Returns (bytes, file) or (None, None): the figure is
+    READ FROM THAT FILE, not measured in this run (PMC passes need rocprofv3 around the process)."""
+    for rnd in ("r03", "r02", "r01"):
+        rel = os.path.join("profiles", f"{rnd}_traffic_{math}.json")
         try:
-            d = json.load(open(f))
+            d = json.load(open(os.path.join(ROOT, rel)))
             if d.get("per_gpu_batch") == batch and d.get("workload") == "dn_train":
-                return d[klass]["traffic_bytes_per_launch"]
+                return d[klass]["traffic_bytes_per_launch"], rel
         except Exception:
             pass
-    return None
+    return None, None
 
 
 MATHS = {
-    # mode: (dtype label, kernel name, fp32-class?)
-    "fp32": ("f32", "conv3x3_mfma_kernel<*,false>", True),
-    "bf16x6": ("f32 (exact 3-term bf16 split, 6 bf16 MFMA products per fp32 product, single-rounding f32 accumulate, f32 planes)",
-               "conv3x3_s3x_kernel", True),
-    "f16x3": ("f32 (2-term fp16 split of power-of-two-scaled operands, 3 fp16 MFMA products per fp32 product, single-rounding f32 accumulate, f32 planes)",
-              "conv3x3_h2x_kernel", True),
-    "bf16x3": ("bf16x3 (hi+lo split MFMA, f32 accumulate, f32 planes)", "conv3x3_mfma_kernel<*,true>", False),
-    "bf16x3_p16": ("bf16x3 (hi+lo split MFMA, f32 accumulate, hi|lo bf16 planes)", "conv3x3_p16_kernel", False),
+    # mode: (dtype label = the arithmetic the path computes in, conv kernel name)
+    "fp32": ("f32 (exact fp32 MFMA)", "conv3x3_mfma_kernel"),
+    "bf16x6": ("f32 emulated exactly on bf16 MFMA (bf16x6: 3-term bf16 split = all 24 significant bits, 6 products per multiply, "
+               "single-rounding f32 accumulate, f32 planes)", "conv3x3_s3x_kernel"),
+    "f16x3": ("f16x3 (f32 planes and f32 accumulate; operands as 2-term fp16 splits of power-of-two-scaled tensors = 22-23 significant "
+              "bits per operand, 3 fp16 MFMA products per multiply; gradients measured at 1.2-1.6x the float64-error of torch's fp32 path)",
+              "conv3x3_h2x_kernel"),
 }
 DEFAULT_MATH = "f16x3"
-MATH_PRODUCTS = {"bf16x6": 6, "f16x3": 3, "bf16x3": 3, "bf16x3_p16": 3}   # bf16 MFMAs per fp32 product
-MATH_BOUND = {"bf16x6": "mfma", "f16x3": "mfma", "bf16x3": "hbm", "bf16x3_p16": "hbm"}  # binding roofline of the conv kernel (DESIGN.md section 6)
+MATH_PRODUCTS = {"bf16x6": 6, "f16x3": 3}   # 16-bit MFMAs per fp32 product
+STEP_BYTES = {("dn", True): 117020.0, ("dn", False): 33420.0, ("sr", True): 124224.0, ("sr", False): 35476.0}   # SURVEY 8(d), per LR pixel
+STEP_FLOP = {("dn", True): 2.62e12, ("dn", False): 8.749e11, ("sr", True): 2.74e12, ("sr", False): 9.140e11}   # per tile
+
+
+def roofline_block(math, prof, batch, kind, train, world, tiles_per_s):
+    """roofline of the dominant kernel (the conv: forward + input-gradient launches) from the HIP-event records of the timed
+    region; `prof` = {0: conv totals, 1: weight-gradient totals} (Engine.profile_read)."""
+    k = prof[0]
+    sec = k["ms"] * 1e-3
+    tf = k["flop"] / sec / 1e12
+    gbs = k["bytes"] / sec / 1e9
+    pmc_ok = train and kind == "dn" and world == 1
+    traffic, tfile = pmc_traffic(math, batch, "conv") if pmc_ok else (None, None)
+    hb = {"achieved": gbs, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBPS}
+    if math == "fp32":   # exact fp32 MFMA: compute-bound by 4-5x (DESIGN.md section 4)
+        roof = {"bound": "mfma", "kernel": MATHS[math][1], "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / FP32_MFMA_PEAK_TFLOPS}
+    else:                # split modes: `nprod` 16-bit MFMAs per fp32 product -> effective matrix peak 2500 / nprod TFLOP/s
+        nprod = MATH_PRODUCTS[math]
+        eff_peak = BF16_MFMA_PEAK_TFLOPS / nprod
+        roof = {"bound": "mfma", "kernel": MATHS[math][1], "achieved": tf, "peak": eff_peak,
+                "unit": f"TFLOP/s (algorithmic fp32 FLOP; {nprod} {'fp16' if math == 'f16x3' else 'bf16'} MFMAs each)", "frac": tf / eff_peak}
+    roof.update({"traffic": traffic, "traffic_from": (tfile + " (committed PMC passes of this workload; not measured in this run)") if tfile else None,
+                 "hbm": hb, "launches": k["launches"], "avg_launch_ms": k["ms"] / k["launches"],
+                 "algorithmic_bytes_per_launch": k["bytes"] / k["launches"], "algorithmic_flop_per_launch": k["flop"] / k["launches"]})
+    if prof[1]["launches"] > 0:
+        w = prof[1]
+        wsec = w["ms"] * 1e-3
+        wt, wfile = pmc_traffic(math, batch, "wgrad") if pmc_ok else (None, None)
+        roof["wgrad_kernel"] = {"achieved_TFLOPs": w["flop"] / wsec / 1e12, "achieved_GBps": w["bytes"] / wsec / 1e9,
+                                "launches": w["launches"], "avg_launch_ms": w["ms"] / w["launches"], "traffic": wt, "traffic_from": wfile}
+    # SURVEY 8(d): whole-step algorithmic bytes / flops per tile (fp32 counting rule) x tiles/s against the peaks
+    step_bytes = STEP_BYTES[(kind, train)] * TILE * TILE
+    step_flop = STEP_FLOP[(kind, train)]
+    per_gpu = tiles_per_s / world
+    roof["whole_step"] = {"algorithmic_GBps": step_bytes * per_gpu / 1e9, "hbm_frac": step_bytes * per_gpu / 1e9 / HBM_PEAK_GBPS,
+                          "algorithmic_TFLOPs": step_flop * per_gpu / 1e12, "fp32_mfma_frac": step_flop * per_gpu / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                          "note": "per GPU; SURVEY.md 8(d) bytes/flops per tile x tiles/s"}
+    return roof
 
 
 def self_launch(args) -> int:
@@ -150,7 +195,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="dn_train", choices=["dn_train", "sr_train", "dn_fwd", "sr_fwd"])
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 32 at N=1, 16 at N>1; sr_fwd: 16)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 32 at every N; sr_fwd: 16)")
     ap.add_argument("--math", default=os.environ.get("XSD_MATH", DEFAULT_MATH), choices=sorted(MATHS),
                     help="MFMA math mode of the conv kernels (include/xsd.h: xsd_set_math); the headline must be fp32-class")
     ap.add_argument("--input-pipeline", action="store_true",
@@ -162,7 +207,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--extra-math", default="bf16x6", choices=sorted(MATHS) + ["none"],
-                    help="second, labelled measurement in another math mode (short run; never the headline)")
+                    help="second, labelled measurement in another math mode (same --steps/--warmup, own roofline; never the headline)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra-math leg")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -198,7 +243,7 @@ def main():
 
     kind, mode = args.workload.split("_")
     train = mode == "train"
-    B = args.batch or (16 if (world > 1 or args.workload == "sr_fwd") else 32)
+    B = args.batch or (16 if args.workload == "sr_fwd" else 32)
     scale = 2 if kind == "sr" else 1
 
     torch.manual_seed(0)  # same seeded default init on every rank (DP replicas start identical)
@@ -269,7 +314,20 @@ def main():
 
     dt, prof = timed(args.warmup, args.steps, not args.no_profile)
 
-    # ---- extra leg (same process, same inputs): another math mode, short run, labelled; never the headline
+    replicas_identical = None
+    if world > 1 and train:     # DDP invariant, checked outside the timed region: every rank holds bit-identical parameters
+        bits = trainer.flat.view(torch.int32).to(torch.int64)
+        h = torch.stack([bits.sum(), (bits * torch.arange(1, bits.numel() + 1, device=dev, dtype=torch.int64)).sum()])   # (wraps: fine, it is a hash)
+        hs = [torch.zeros_like(h) for _ in range(world)]
+        if backend == "nccl":
+            dist.all_gather(hs, h)
+        else:
+            hc = [t.cpu() for t in hs]
+            dist.all_gather(hc, h.cpu())
+            hs = hc
+        replicas_identical = all(bool(torch.equal(t.cpu(), hs[0].cpu())) for t in hs)
+
+    # ---- extra leg (same process, same inputs): another math mode over the same --steps/--warmup, labelled; never the headline
     extra = None
     xm = None if (args.no_extra or world > 1 or args.extra_math in ("none", args.math)) else args.extra_math   # N=1 only
     if xm is not None:
@@ -279,16 +337,17 @@ def main():
         with torch.no_grad():
             y_x = model(x[:2])
         err = float((y_x - y_head).abs().max())
-        nx = max(1, min(args.steps, 4))
-        dte, _ = timed(1, nx, False)
-        extra = {"math": xm, "dtype": MATHS[xm][0], "fp32_class": MATHS[xm][2], "value": B * world * nx / dte, "unit": "tiles/s",
-                 "steps": nx, "ms_per_step": 1e3 * dte / nx, "max_abs_output_diff_vs_" + args.math: err,
-                 "note": "not the headline: reported for comparison only"}
+        dte, profe = timed(args.warmup, args.steps, not args.no_profile)
+        extra = {"math": xm, "dtype": MATHS[xm][0], "value": B * world * args.steps / dte, "unit": "tiles/s",
+                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dte / args.steps,
+                 "max_abs_output_diff_vs_" + args.math: err, "note": "not the headline: the strict mode, reported for comparison"}
+        if profe is not None and profe[0]["launches"] > 0:
+            extra["roofline"] = roofline_block(xm, profe, B, kind, train, world, B * world * args.steps / dte)
         model.set_math(args.math)
 
     if rank == 0:
         tiles = B * world * args.steps
-        dtype, kname, f32class = MATHS[args.math]
+        dtype, kname = MATHS[args.math]
         out = {
             "metric": "XMM 512x512 tiles/sec (train step)" if train else "XMM 512x512 tiles/sec (forward)",
             "value": tiles / dt, "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -299,48 +358,12 @@ def main():
                                     "dn_fwd": "XMM-DeNoise forward", "sr_fwd": "XMM-SuperRes 2x generator forward"}[args.workload],
                        "tile": f"1x{TILE}x{TILE}", "per_gpu_batch": B, "global_batch": B * world,
                        "layers": "RRDB generator, 32 filters x 4 blocks (res/configs/models.toml)", "math": args.math,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "dist_backend": backend if world > 1 else None},
         }
+        if replicas_identical is not None:
+            out["replicas_identical"] = replicas_identical
         if prof is not None and prof[0]["launches"] > 0:
-            k = prof[0]
-            sec = k["ms"] * 1e-3
-            tf = k["flop"] / sec / 1e12
-            gbs = k["bytes"] / sec / 1e9
-            traffic = pmc_traffic(args.math, B, "conv") if (train and kind == "dn" and world == 1) else None
-            if args.math == "fp32":
-                # exact fp32 MFMA: compute-bound by 4-5x
-                roof = {"bound": "mfma", "kernel": kname, "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                        "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBPS}}
-            else:
-                # split modes: `nprod` bf16 MFMAs per fp32 product -> effective matrix peak 2500 / nprod TFLOP/s
-                nprod = MATH_PRODUCTS[args.math]
-                eff_peak = BF16_MFMA_PEAK_TFLOPS / nprod
-                mf = {"achieved": tf, "peak": eff_peak, "unit": f"TFLOP/s (algorithmic fp32 FLOP; {nprod} {'fp16' if args.math == 'f16x3' else 'bf16'} MFMAs each)",
-                      "frac": tf / eff_peak}
-                hb = {"achieved": gbs, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBPS}
-                if MATH_BOUND[args.math] == "hbm":
-                    roof = {"bound": "hbm", "kernel": kname, **hb, "traffic": traffic, "mfma": mf}
-                else:
-                    roof = {"bound": "mfma", "kernel": kname, **mf, "traffic": traffic, "hbm": hb}
-            roof.update({"launches": k["launches"], "avg_launch_ms": k["ms"] / k["launches"],
-                         "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
-                         "algorithmic_flop_per_launch": k["flop"] / k["launches"]})
-            if prof[1]["launches"] > 0:
-                w = prof[1]
-                wsec = w["ms"] * 1e-3
-                roof["wgrad_kernel"] = {"achieved_TFLOPs": w["flop"] / wsec / 1e12, "achieved_GBps": w["bytes"] / wsec / 1e9,
-                                        "launches": w["launches"], "avg_launch_ms": w["ms"] / w["launches"],
-                                        "traffic": pmc_traffic(args.math, B, "wgrad") if (train and kind == "dn" and world == 1) else None}
-            # whole-step algorithmic bytes / flops per tile (fp32 counting rule) x tiles/s against the peaks
-            step_bytes = {("dn", True): 117020.0, ("dn", False): 33420.0, ("sr", True): 124224.0, ("sr", False): 35476.0}[(kind, train)] * TILE * TILE
-            step_flop = {("dn", True): 2.62e12, ("dn", False): 8.749e11, ("sr", True): 2.74e12, ("sr", False): 9.140e11}[(kind, train)]
-            per_gpu = tiles / dt / world
-            roof["whole_step"] = {"algorithmic_GBps": step_bytes * per_gpu / 1e9, "hbm_frac": step_bytes * per_gpu / 1e9 / HBM_PEAK_GBPS,
-                                  "algorithmic_TFLOPs": step_flop * per_gpu / 1e12,
-                                  "fp32_mfma_frac": step_flop * per_gpu / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                                  "note": "per GPU; SURVEY.md 8(d) bytes/flops per tile x tiles/s"}
-            out["roofline"] = roof
+            out["roofline"] = roofline_block(args.math, prof, B, kind, train, world, tiles / dt)
         if extra is not None:
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:

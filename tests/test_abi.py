@@ -118,8 +118,7 @@ def test_bench_contract_without_gpu():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     assert set(bench.MATHS) == set(Engine.MATH)
-    assert bench.MATHS[bench.DEFAULT_MATH][2] is True                      # headline math is fp32-class
-    assert not bench.MATHS["bf16x3_p16"][2] and not bench.MATHS["bf16x3"][2]
+    assert bench.DEFAULT_MATH == "f16x3" and "22-23 significant" in bench.MATHS["f16x3"][0]   # the headline's dtype label says what it is
     calls = {}
 
     def fake_run(cmd, env=None):

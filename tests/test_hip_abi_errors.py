@@ -38,6 +38,18 @@ def test_status_codes_and_messages():
     with pytest.raises(XsdError, match="preceding forward"):
         e.backward(torch.zeros(1, 1, 16, 32, device="cuda"), torch.zeros_like(flat))
     assert L.xsd_set_math(e.h, 7) < 0 and b"math mode" in L.xsd_last_error()
+    assert L.xsd_set_math(e.h, 1) < 0 and L.xsd_set_math(e.h, 2) < 0            # the 16-bit-significand modes are gone
+    # the split modes address a plane's batch slice with 32-bit BYTE offsets: 2^24 pixels x 128 B no longer fit -> refused
+    # up front, with a message, instead of range-checked loads returning zeros; the exact-fp32 mode takes it
+    e.set_math("f16x3")
+    with pytest.raises(XsdError, match="too large for math modes"):
+        e.forward(torch.zeros(1, 1, 4096, 4096, device="cuda"))
+    e.set_math("bf16x6")
+    e.pack(flat)
+    with pytest.raises(XsdError, match="too large for math modes"):
+        e.forward(torch.zeros(1, 1, 4096, 4096, device="cuda"))
+    e.set_math("f16x3")
+    e.pack(flat)
     assert L.xsd_forward(e.h, None, None, 1, 16, 32, 0, None) < 0
     assert L.xsd_normalize(None, None, 0, 1.0, 0, 0, None) < 0
     assert L.xsd_mask_pad_normalize(None, 1, None, None, 1, 8, 8, 16, 1, -1.0, 9, None) < 0

@@ -13,13 +13,13 @@ from util_hip import nchw_to_planes, planes_to_nchw, ptr_array
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["fp32", "bf16x6", "f16x3", "bf16x3", "bf16x3_p16"])
+@pytest.fixture(scope="module", params=["fp32", "bf16x6", "f16x3"])
 def eng(request):
     from xmm_superres_denoise.engine import Engine
     math = request.param
     e = Engine("dn", 1, 1, 32, 1)
     e.set_math(math)
-    e.tol = {"fp32": 2e-5, "bf16x6": 2e-5, "f16x3": 2e-5, "bf16x3": 6e-5, "bf16x3_p16": 1e-4}[math]   # bf16x3: <= 3*2^-16 per product, random-sign sums
+    e.tol = 2e-5
     return e
 
 

@@ -74,3 +74,47 @@ def test_two_ranks_on_hip_engine_match_single_process_full_batch(tmp_path, math,
         assert np.abs(res[0]["params"][s] - tr.flat.cpu().numpy()).max() <= 2e-5   # Adam: |update| <= lr = 1e-3 per step
     # the update moved the weights at all (lr 1e-3, 2 steps)
     assert np.abs(res[0]["params"][-1] - res[0]["params"][0]).max() > 1e-4
+
+
+def test_bench_two_ranks_gloo_on_one_gpu():
+    """`python bench.py --gpus 2` as the driver launches it for N > 1 (self-launching here): two ranks, one process each, the
+    DP train step with the staged all-reduce; over RCCL when two GPUs are visible, else both ranks share cuda:0 over gloo.
+    The JSON line carries the whole-job value and the DDP invariant (bit-identical replicas after the timed steps)."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env["XSD_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--no-extra", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0, out[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-3000:]          # rank 0 prints exactly one JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and d["steps"] == 2
+    assert d["config"]["per_gpu_batch"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["replicas_identical"] is True
+    assert abs(d["value"] - 4 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]      # value = all ranks' tiles / max-over-ranks time
+    assert d["roofline"]["launches"] > 0
+
+
+def test_train_driver_two_ranks(tmp_path):
+    """train.py (the `train.py fit` counterpart, reference train.py:141-155 for the DDP part) under torch.distributed.run with
+    two ranks: honours XSD_DIST_BACKEND like bench.py, trains, reduces the validation states, writes the checkpoint."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=os.path.join(root, "xmm-superres-denoise_amd"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env["XSD_DIST_BACKEND"] = "gloo"
+    ck = os.path.join(tmp_path, "dp.ckpt")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "xmm_superres_denoise.train", "fit", "--lr-res", "64", "--batch-size", "4",
+           "--steps", "3", "--val-batches", "1", "--checkpoint", ck]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0, out[-3000:]
+    assert out.count("train/loss") == 3 and "validation:" in out and os.path.exists(ck)

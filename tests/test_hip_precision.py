@@ -1,21 +1,29 @@
-"""Are the split math modes fp32-CLASS?  "bf16x6" (exact 3-term bf16 split, six products, MFMA accumulation) and "f16x3" (two-term
-fp16 split of power-of-two-scaled operands, three products; the default) are measured against a float64
-evaluation of the same network, next to the two things that define "the reference's precision": torch's own fp32 path on
-the CPU (the reference's nn.Conv2d arithmetic, rrdb_blocks.py:27-54) and this engine's exact-fp32 MFMA mode.
-The claim tested: error(bf16x6 vs float64) <= error(torch fp32 vs float64), on single layers, on the golden cases and on a
-512 x 512 four-block generator, forward and backward.  The 16-bit modes (bf16x3, bf16x3_p16) fail the same inequality by an
-order of magnitude, which is why they are not the headline (asserted too, so the distinction stays measured)."""
+"""How close to fp32 are the two split math modes?  "bf16x6" (strict: exact 3-term bf16 split, six products, MFMA accumulation)
+and "f16x3" (default and benchmark headline: two-term fp16 split of power-of-two-scaled operands, 22-23 significant bits per
+operand, three products) are measured against a float64 evaluation of the same network, next to the two things that define
+"the reference's precision": torch's own fp32 path on the CPU (the reference's nn.Conv2d arithmetic, rrdb_blocks.py:27-54)
+and this engine's exact-fp32 MFMA mode (bitwise an fp32 fma chain).
+
+What the asserts enforce (and include/xsd.h, bench.py's `dtype` label and DESIGN.md section 4 claim no more than this):
+  bf16x6 : error <= torch fp32 AND <= the exact-fp32 mode -- forward and backward, flat-gradient rms and the worst
+           per-tensor rms, on every seed and size below.
+  f16x3  : forward error <= torch fp32 and <= the exact-fp32 mode; backward (flat-gradient rms, dL/dx rms, worst per-tensor
+           rms) <= 2 x torch fp32 and <= 1.25 x the exact-fp32 mode, worst case over all seeds and sizes (measured 1.2-1.6 x
+           torch, 0.95-1.0 x the fma chain) -- "at the level of an fp32 fma chain", not "at least as accurate as torch".
+  every mode: per-tensor max error of every parameter gradient and of dL/dx at 512 x 512, batch 2, below 2e-4 of the
+           tensor's largest entry on every row without a LeakyReLU flip candidate (util_hip.assert_grad_close).
+Run with `pytest -s` to get the tables; the log of the round is committed under profiles/."""
 import os
 
 import numpy as np
 import pytest
 import torch
 
-SPLITS = ("bf16x6", "f16x3")   # the two fp32-class split modes: each must beat torch fp32 AND the exact-fp32 MFMA mode
+SPLITS = ("bf16x6", "f16x3")   # the two split modes
 
 import gen_common as gc
 from oracle import oracle
-from util_hip import build_module, load_case, nchw_to_planes, planes_to_nchw, ptr_array
+from util_hip import FLIP_LOG, assert_grad_close, build_module, flip_candidates, load_case, nchw_to_planes, planes_to_nchw, ptr_array
 
 pytestmark = pytest.mark.gpu
 
@@ -44,7 +52,7 @@ def test_mfma_accumulation_is_single_rounding():
     errs = {"torch_fp32": _rms(t32, ref)}
     xin = nchw_to_planes(x)
     wd, bd = torch.from_numpy(w).cuda(), torch.from_numpy(b).cuda()
-    for math in ("fp32", "bf16x6", "f16x3", "bf16x3"):
+    for math in ("fp32", "bf16x6", "f16x3"):
         e = Engine("dn", 1, 1, 32, 1)
         e.set_math(math)
         out = [torch.full((B, H, W, 32), float("nan"), device="cuda")]
@@ -57,7 +65,6 @@ def test_mfma_accumulation_is_single_rounding():
     for m in SPLITS:
         assert errs[m] <= 0.5 * errs["fp32"], m
         assert errs[m] <= 2.0 * errs["torch_fp32"], m
-    assert errs["bf16x3"] > 5 * errs["torch_fp32"]          # 16-bit significands: not fp32-class
 
 
 @pytest.mark.parametrize("name,kind", [("dn_nf32_b4_32x32", "dn"), ("sr_nf32_b4_24x40", "sr")])
@@ -66,7 +73,7 @@ def test_golden_cases_error_vs_float64(name, kind):
     y64 = oracle.torch_forward(kind, 32, blocks, _state_t(state, torch.float64), torch.from_numpy(x).double(), num_upsample=nup).numpy()
     y32 = oracle.torch_forward(kind, 32, blocks, _state_t(state, torch.float32), torch.from_numpy(x), num_upsample=nup).numpy()
     errs = {"torch_fp32": _rms(y32, y64), "golden(reference fp32)": _rms(z["y"], y64)}
-    for math in ("fp32", "bf16x6", "f16x3", "bf16x3_p16"):
+    for math in ("fp32", "bf16x6", "f16x3"):
         m = build_module(kind, blocks, nup, state).set_math(math)
         with torch.no_grad():
             errs[math] = _rms(m(torch.from_numpy(x).cuda()).cpu().numpy(), y64)
@@ -75,7 +82,6 @@ def test_golden_cases_error_vs_float64(name, kind):
         assert errs[m] <= errs["torch_fp32"], m
         assert errs[m] <= errs["golden(reference fp32)"], m
         assert errs[m] <= errs["fp32"], m
-    assert errs["bf16x3_p16"] > 5 * errs["torch_fp32"]
 
 
 def test_f16x3_survives_extreme_ranges():
@@ -118,11 +124,33 @@ def test_f16x3_survives_extreme_ranges():
         assert mine <= 1.5 * torch32, name                  # and in torch fp32's class on the same data
 
 
-def _net_errors(size, blocks, seed, with_grad):
+MODES = ("fp32", "bf16x6", "f16x3")
+
+
+def _per_tensor(flat, ref, shapes):
+    """(worst per-tensor relative rms, worst per-tensor max |err| / max |ref|, name of that tensor) over the parameter tensors"""
+    off, worst_rms, worst_max, who = 0, 0.0, 0.0, ""
+    for name, shp in shapes.items():
+        k = int(np.prod(shp))
+        a, r = np.asarray(flat[off:off + k], np.float64), np.asarray(ref[off:off + k], np.float64)
+        off += k
+        worst_rms = max(worst_rms, _rms(a, r))
+        mx = float(np.abs(a - r).max() / (np.abs(r).max() + 1e-300))
+        if mx > worst_max:
+            worst_max, who = mx, name
+    return worst_rms, worst_max, who
+
+
+def _net_errors(size, blocks, seed, with_grad, batch=1, flip_aware=False):
+    """DN generator, `blocks` RRDB blocks, `batch` tiles of size x size, seeded weights and input; gradient of the linear
+    functional <dy, y> (no loss discontinuity).  Returns {mode: {y, g, dx, t_rms, t_max}} relative to float64 torch, with
+    torch's own fp32 path as one of the modes.  flip_aware: also hold every mode's every gradient tensor and dL/dx to the
+    row-wise tolerance of the golden tests (2e-4 / 4e-4 of the tensor's largest entry off the flip-candidate rows)."""
     kind = "dn"
     state = gc.make_state(kind, 32, blocks, seed, gain=1.0)
-    x = gc.make_input((1, 1, size, size), seed + 1)
-    dy = (gc.make_input((1, 1, size, size), seed + 2) - 0.5).astype(np.float32) / (size * size)
+    x = gc.make_input((batch, 1, size, size), seed + 1)
+    dy = (gc.make_input((batch, 1, size, size), seed + 2) - 0.5).astype(np.float32) / (batch * size * size)
+    shapes = gc.rrdb_param_shapes(kind, 32, blocks)
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
     def torch_path(dtype):
@@ -139,44 +167,103 @@ def _net_errors(size, blocks, seed, with_grad):
     y64, g64, dx64 = torch_path(torch.float64)
     y32, g32, dx32 = torch_path(torch.float32)
     inside = (y64 > 0) & (y64 < 1)          # the clamp hides errors where it saturates: compare where it is the identity
-    out = {"torch_fp32": {"y": _rms(y32[inside], y64[inside])}}
-    if with_grad:
-        out["torch_fp32"].update(g=_rms(g32, g64), dx=_rms(dx32, dx64))
-    for math in ("fp32", "bf16x6", "f16x3", "bf16x3_p16"):
+
+    def record(y, g, dx):
+        rec = {"y": _rms(y[inside], y64[inside])}
+        if with_grad:
+            t_rms, t_max, who = _per_tensor(g, g64, shapes)
+            rec.update(g=_rms(g, g64), dx=_rms(dx, dx64), t_rms=t_rms, t_max=t_max, t_max_at=who,
+                       dx_max=float(np.abs(dx.astype(np.float64) - dx64).max() / np.abs(dx64).max()))
+        return rec
+
+    out = {"torch_fp32": record(y32, g32, dx32)}
+    cand = None
+    if flip_aware:
+        cand, _ = flip_candidates(kind, blocks, state, x, np.zeros_like(x), 1)      # LeakyReLU candidates (the functional has no L1 sign)
+    for math in MODES:
         m = build_module(kind, blocks, 1, state).set_math(math)
         eng = m._get_engine(torch.device("cuda", 0))
         eng.pack(m.flat_parameters())
         y = eng.forward(torch.from_numpy(x).cuda(), save_for_backward=with_grad)
-        rec = {"y": _rms(y.cpu().numpy()[inside], y64[inside])}
+        g = dx = None
         if with_grad:
             grads = torch.empty_like(m.flat_parameters())
-            dx = eng.backward(torch.from_numpy(dy).cuda(), grads, need_dx=True)
-            rec.update(g=_rms(grads.cpu().numpy(), g64), dx=_rms(dx.cpu().numpy(), dx64))
-        out[math] = rec
+            dx = eng.backward(torch.from_numpy(dy).cuda(), grads, need_dx=True).cpu().numpy()
+            g = grads.cpu().numpy()
+        out[math] = record(y.cpu().numpy(), g, dx)
+        if flip_aware:
+            mark = len(FLIP_LOG)
+            assert_grad_close(dx.reshape(-1, size), dx64.reshape(-1, size), "dx", tight=4e-4, loose=5e-2, candidates=cand, n_out_candidates=0)
+            off = 0
+            for name, shp in shapes.items():
+                k = int(np.prod(shp))
+                assert_grad_close(g[off:off + k].reshape(shp), g64[off:off + k].reshape(shp), name, tight=2e-4, candidates=cand, n_out_candidates=0)
+                off += k
+            out[math]["rows_needing_flip_allowance"] = sum(r["rows_over_tight"] for r in FLIP_LOG[mark:])
+        del m, eng
+        torch.cuda.empty_cache()
     return out, float(inside.mean())
+
+
+def _table(title, errs):
+    keys = [k for k in ("y", "g", "dx", "t_rms", "t_max", "dx_max") if k in errs["torch_fp32"]]
+    print(title)
+    print("    %-11s" % "mode" + "".join("%11s" % k for k in keys) + "   worst tensor")
+    for mode, rec in errs.items():
+        print("    %-11s" % mode + "".join("%11.3e" % rec[k] for k in keys) + "   " + str(rec.get("t_max_at", "")) +
+              ("   (rows needing the flip allowance: %d)" % rec["rows_needing_flip_allowance"] if "rows_needing_flip_allowance" in rec else ""))
 
 
 def test_full_size_forward_error_vs_float64():
     """BASELINE tile size, BASELINE depth: 1 x 512 x 512, 4 RRDB blocks (36 dense blocks, K up to 1440 per conv)."""
     errs, frac = _net_errors(512, 4, 7001, with_grad=False)
-    print(f"512^2 x 4 blocks, forward rms error vs float64 ({100 * frac:.0f}% of pixels unclamped):", errs)
+    _table(f"512^2 x 4 blocks, forward rms error vs float64 ({100 * frac:.0f}% of pixels unclamped):", errs)
     for m in SPLITS:
         assert errs[m]["y"] <= errs["torch_fp32"]["y"], m
         assert errs[m]["y"] <= errs["fp32"]["y"], m
-    assert errs["bf16x3_p16"]["y"] > 5 * errs["torch_fp32"]["y"]
 
 
-def test_backward_error_vs_float64():
-    """256 x 256, 4 blocks, gradient of the linear functional <dy, y> (no loss discontinuity): every parameter gradient and
-    dL/dx against float64 autograd (LeakyReLU' / clamp-mask flips hit every fp32 path alike)."""
-    errs, frac = _net_errors(256, 4, 7101, with_grad=True)
-    print(f"256^2 x 4 blocks, rms errors vs float64 ({100 * frac:.0f}% of pixels unclamped):", errs)
-    for key in ("y", "g", "dx"):
-        # bf16x6 (exact operands): strictly below both fp32 yard-sticks.  f16x3 (22-23 significant bits per operand, the
-        # truncation feeds every layer of the gradient chain): at the level of an fp32 fma chain -- never above this engine's
-        # bit-exact fp32 MFMA mode, and within 2x of torch's CPU kernel, whose blocked partial sums are the most accurate
-        # fp32 evaluation here (measured 1.2x on the parameter gradients, 1.6x on dL/dx; forward: below torch, asserted above)
-        assert errs["bf16x6"][key] <= errs["torch_fp32"][key], key
-        assert errs["bf16x6"][key] <= errs["fp32"][key], key
-        assert errs["f16x3"][key] <= errs["fp32"][key], key
-        assert errs["f16x3"][key] <= (1.0 if key == "y" else 2.0) * errs["torch_fp32"][key], key
+# (size, batch, seed, flip-aware per-tensor check): four seeds at 256 x 256, two at the BASELINE tile size with batch 2
+BACKWARD_CASES = [(256, 1, 7101, False), (256, 1, 7201, False), (256, 1, 7301, False), (256, 1, 7401, False),
+                  (512, 2, 7501, True), (512, 2, 7601, False)]
+_BWD_RESULTS = {}
+
+
+@pytest.mark.parametrize("size,batch,seed,flip_aware", BACKWARD_CASES)
+def test_backward_error_vs_float64(size, batch, seed, flip_aware):
+    """4 blocks, gradient of the linear functional <dy, y>: every parameter gradient and dL/dx against float64 autograd, per
+    case.  The 512 x 512, batch 2 case with flip_aware additionally checks EVERY gradient tensor row-wise (a wrong tile-edge
+    term in one layer's dW would vanish in a flat rms over 1.67 M parameters; LeakyReLU' flips hit every fp32 path alike and
+    are allowed only on the rows a float64 evaluation names).  The relative bars are asserted per case here and on the worst
+    case over all cases in test_backward_worst_case_summary."""
+    errs, frac = _net_errors(size, 4, seed, with_grad=True, batch=batch, flip_aware=flip_aware)
+    _BWD_RESULTS[(size, batch, seed)] = errs
+    _table(f"{size}^2 x {batch} tile(s) x 4 blocks, seed {seed}: errors vs float64 ({100 * frac:.0f}% of pixels unclamped):", errs)
+    t32, f32 = errs["torch_fp32"], errs["fp32"]
+    for key in ("y", "g", "dx", "t_rms"):
+        assert errs["bf16x6"][key] <= t32[key], key          # strict mode: below both fp32 yard-sticks
+        assert errs["bf16x6"][key] <= f32[key], key
+        assert errs["f16x3"][key] <= 1.25 * f32[key], key     # headline mode: at the level of the fp32 fma chain ...
+        assert errs["f16x3"][key] <= (1.0 if key == "y" else 2.0) * t32[key], key   # ... and within 2x of torch (forward: below it)
+    for mode in MODES:                                        # nobody is anywhere near north_star's 1e-3
+        assert errs[mode]["t_max"] < 2e-2 and errs[mode]["g"] < 1e-4 and errs[mode]["dx"] < 1e-4, mode
+
+
+def test_backward_worst_case_summary():
+    """The same bars on the WORST ratio over every seed and size that ran (what DESIGN.md section 4 quotes)."""
+    if not _BWD_RESULTS:
+        pytest.skip("test_backward_error_vs_float64 did not run in this session")
+    worst = {}
+    for errs in _BWD_RESULTS.values():
+        for mode in SPLITS:
+            for key in ("y", "g", "dx", "t_rms"):
+                for ref in ("torch_fp32", "fp32"):
+                    k = (mode, key, ref)
+                    worst[k] = max(worst.get(k, 0.0), errs[mode][key] / errs[ref][key])
+    print(f"worst error ratios over {len(_BWD_RESULTS)} cases (mode / yard-stick):")
+    for (mode, key, ref), v in sorted(worst.items()):
+        print(f"    {mode:7s} {key:6s} vs {ref:10s}: {v:.3f}")
+    for key in ("y", "g", "dx", "t_rms"):
+        assert worst[("bf16x6", key, "torch_fp32")] <= 1.0 and worst[("bf16x6", key, "fp32")] <= 1.0
+        assert worst[("f16x3", key, "fp32")] <= 1.25
+        assert worst[("f16x3", key, "torch_fp32")] <= (1.0 if key == "y" else 2.0)

@@ -149,3 +149,38 @@ def test_epoch_metric_states_are_reduced_not_averaged():
         assert abs(ret[0][k] - v) < 1e-6, (k, ret[0][k], v)
     mean_of_rank_psnr = 0.5 * (10 * np.log10(0.6 ** 2 / 0.005) + 10 * np.log10(0.9 ** 2 / 0.080))
     assert abs(ret[0]["psnr"] - mean_of_rank_psnr) > 0.1
+
+
+def _uneven_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xmm_superres_denoise.models.model import _mean_over_ranks
+    from xmm_superres_denoise.utils.loss_functions import EpochState
+    st = EpochState()
+    if rank == 0:       # rank 1's validation shard is empty: it must still enter the three collectives
+        st.add(torch.tensor([0, 0.10, 0.5, 0, 0.80, 0.70, 0.005, 0.10, 0.60], dtype=torch.float32), n=1000, nimg=2)
+    st.sync()
+    vals = {k: float(v) for k, v in st.compute().items()}
+    empty = EpochState()
+    empty.sync()        # nobody saw a batch: the collectives still match and the state stays empty
+    fb = _mean_over_ranks({"b": torch.tensor(float(rank)), "a": torch.tensor(10.0 + rank)})
+    ret[rank] = (vals, empty.acc is None, {k: float(v) for k, v in fb.items()})
+    dist.destroy_process_group()
+
+
+def test_epoch_state_sync_with_an_empty_rank_does_not_hang():
+    """EpochState.sync() used to return early on a rank without batches while the others entered three
+    all_reduces (a hang with uneven validation shards).  Now every rank takes part with the identity state; collections
+    without a sync() are mean-reduced over the ranks (Model._on_epoch_end's fallback)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_uneven_worker, args=(2, port, ret), nprocs=2, join=True)
+    v0, e0, f0 = ret[0]
+    v1, e1, f1 = ret[1]
+    assert v0 == v1 and e0 and e1
+    assert abs(v0["l2"] - 0.005) < 1e-9 and abs(v0["l1"] - 0.10) < 1e-7 and abs(v0["psnr"] - 10 * np.log10(0.6 ** 2 / 0.005)) < 1e-5
+    assert f0 == f1 == {"a": 10.5, "b": 0.5}

@@ -143,9 +143,19 @@ def check(asm_text, NLOADS=15):
     return len(body)
 
 
+def makefile_flags():
+    """the device-code flags of csrc/Makefile (`make flags` prints $(CXXFLAGS)), so that this check compiles exactly what the
+    build compiles; -fPIC / warnings are irrelevant to the generated device code and dropped"""
+    out = subprocess.run(["make", "-s", "-C", CSRC, "flags"], check=True, stdout=subprocess.PIPE, text=True).stdout.split()
+    keep = [f for f in out if not f.startswith("-W") and f != "-fPIC"]
+    assert any(f.startswith("--offload-arch=") for f in keep) and "-O3" in keep, keep
+    return keep
+
+
 def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     kernels = KERNELS
+    flags = makefile_flags()
     extra = os.environ.get("XSD_CHECK_FLAGS", "").split()          # experiment builds: e.g. XSD_CHECK_FLAGS=-DV3_TH_ROWS=8
     if os.environ.get("XSD_CHECK_ONLY"):                            # "wgrad_h2x.hip:19" -> that kernel with that load count
         name, n = os.environ["XSD_CHECK_ONLY"].split(":")
@@ -153,8 +163,7 @@ def main():
     for src, nloads in kernels:
         with tempfile.TemporaryDirectory() as d:
             out = os.path.join(d, "k.s")
-            subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",   # the flags of csrc/Makefile
-                            "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out] + extra, check=True, stderr=subprocess.DEVNULL)
+            subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out] + extra, check=True, stderr=subprocess.DEVNULL)
             text = open(out).read()
             n = check(text, nloads)
             # no register spills: a scratch reload under these kernels' memory load is a ~4 us round trip, and the ones hipcc

@@ -1,7 +1,6 @@
 // aux_kernels.hip -- the HBM-bound kernels around the MFMA convs: edge layers (Cin=1 / Cout=1), loss, Adam,
 // weight repack, and the input transforms (detector mask, centred pad, Normalize, ImageUpsample).
 // Each kernel cites the reference code it replaces.
-#include "p16.h"
 #include "xsd_kernels.h"
 #include "xsd_aux.h"
 #include "xsd_split.h"
@@ -21,7 +20,6 @@ __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams
     // weights live in registers, and the row is swept two pixels per thread at a time (no per-pixel division).
     __shared__ float srow[3][EDGE_MAX_W + 2];
     const int q = threadIdx.x & 7, px0 = threadIdx.x >> 3;
-    const int ppos = 16 * (q & 1) + 4 * (q >> 1); // P16 position of channel 4q (p16.h)
     f32x4 w4[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) w4[tap] = *reinterpret_cast<const f32x4*>(P.w + tap * 32 + q * 4);
@@ -47,13 +45,11 @@ __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ((m >> i) & 1u) ? v[i] : v[i] * P.mslope;
             } else if (P.mask) {
-                const f32x4 m = P.p16 ? p16_load4(reinterpret_cast<const char*>(P.mask + o), ppos)
-                                      : *reinterpret_cast<const f32x4*>(P.mask + o + q * 4);
+                const f32x4 m = *reinterpret_cast<const f32x4*>(P.mask + o + q * 4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : v[i] * P.mslope;
             }
-            if (P.p16) p16_store4(reinterpret_cast<char*>(P.out + o), ppos, v);
-            else *reinterpret_cast<f32x4*>(P.out + o + q * 4) = v;
+            *reinterpret_cast<f32x4*>(P.out + o + q * 4) = v;
         }
     }
 }
@@ -63,14 +59,12 @@ __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams
 // input-gradient of conv_first).  8 lanes per pixel, each 4 channels x 9 taps, xor-shuffle reduction over the 8 lanes.
 // Algorithmic bytes/px: 128 read (+4 skip) + 4..8 written.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool P16>
 __global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeReduceParams P)
 {
     // Block = (image, 32-pixel column strip, band of EDGE_BAND rows).  Thread = (column, 4-channel quad) walking down
     // the band with a three-row register window: every feature pixel is fetched 3 times (left / centre / right thread)
     // instead of 9, and no per-pixel division is needed.
     const int q = threadIdx.x & 7, px = threadIdx.x >> 3;
-    const int pos = 16 * (q & 1) + 4 * (q >> 1);
     f32x4 w4[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) w4[tap] = *reinterpret_cast<const f32x4*>(P.w + tap * 32 + q * 4);
@@ -85,7 +79,7 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeReduceParams
         auto load = [&](int yy, int xx) { // branch-free: out-of-image taps read the image's first pixel and are zeroed
             const bool ok = yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
             const float* pxp = fb + (ok ? ((long long)yy * P.W + xx) * 32 : 0);
-            const f32x4 v = P16 ? p16_load4(reinterpret_cast<const char*>(pxp), pos) : *reinterpret_cast<const f32x4*>(pxp + q * 4);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(pxp + q * 4);
             const float m = ok ? 1.f : 0.f;
             return v * m;
         };
@@ -128,7 +122,6 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeReduceParams
 //  conv_last : f = trunk features, s = dy -> dW[0][c][tap] = out[8-tap][c], db[0] = ssum
 // Deterministic two-stage reduction (per-block partials, then edge_wgrad_final_kernel).
 // ---------------------------------------------------------------------------------------------------------------
-template <bool P16>
 __global__ __launch_bounds__(256) void edge_wgrad_kernel(const EdgeWgradParams P)
 {
     // One image row per block iteration: the three rows of s around it are staged (zero padded) in LDS, then 8 threads
@@ -136,7 +129,6 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const EdgeWgradParams P
     __shared__ float red[256 * 4];
     __shared__ float srow[3][EDGE_MAX_W + 2];
     const int q = threadIdx.x & 7, px0 = threadIdx.x >> 3;
-    const int pos = 16 * (q & 1) + 4 * (q >> 1);
     f32x4 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -154,8 +146,7 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const EdgeWgradParams P
         __syncthreads();
         const float* frow = P.f + (long long)row * P.W * 32;
         auto load = [&](int x) {
-            return P16 ? p16_load4(reinterpret_cast<const char*>(frow + (long long)x * 32), pos)
-                       : *reinterpret_cast<const f32x4*>(frow + (long long)x * 32 + q * 4);
+            return *reinterpret_cast<const f32x4*>(frow + (long long)x * 32 + q * 4);
         };
         auto use = [&](int x, const f32x4& fv) {
             bs += fv;
@@ -313,81 +304,7 @@ __global__ void pack_weights_kernel(const float* params, const PackDesc* descs, 
     }
 }
 
-// bf16x3 panels (conv3x3_mfma_kernel<*, SPLIT=true>): 16-bit elements [tap][s2][hi|lo][lane = h*32 + c][j], the k index
-// of element j is 16*s2 + 8*h + j; forward/dgrad channel maps as in pack_weights_kernel.  Same byte size per panel.
-__global__ void pack_weights_split_kernel(const float* params, const PackDesc* descs, unsigned short* fwd, unsigned short* bwd)
-{
-    const PackDesc d = descs[blockIdx.y];
-    const int ns = d.cin / 32, nn = d.cout / 32;
-    const int PE = 2 * PANEL_FLOATS; // 18,432 16-bit elements per panel
-    const long long total = (long long)ns * nn * PE;
-    const float* W = params + d.src_w;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        int r = (int)(e % PE);
-        const int panel = (int)(e / PE);
-        const int j = r & 7; r >>= 3;
-        const int c = r & 31; r >>= 5;
-        const int h = r & 1; r >>= 1;
-        const int part = r & 1; r >>= 1;
-        const int s2 = r & 1; r >>= 1;
-        const int tap = r;
-        const int k = 16 * s2 + 8 * h + j;
-        float wf, wb;
-        {
-            const int n = panel / ns, s = panel % ns;
-            const int oc = d.shuffle ? (4 * c + n) : (32 * n + c);
-            wf = W[((long long)oc * d.cin + 32 * s + k) * 9 + tap];
-        }
-        {
-            const int s = panel / nn, n = panel % nn;
-            const int oc = d.shuffle ? (4 * k + n) : (32 * n + k);
-            wb = d.bwd_scale * W[((long long)oc * d.cin + 32 * s + c) * 9 + (8 - tap)];
-        }
-        const __bf16 fh = (__bf16)wf, bh = (__bf16)wb;
-        const __bf16 fl = (__bf16)(wf - (float)fh), bl = (__bf16)(wb - (float)bh);
-        fwd[2 * d.dst_fwd + e] = __builtin_bit_cast(unsigned short, part ? fl : fh);
-        bwd[2 * d.dst_bwd + e] = __builtin_bit_cast(unsigned short, part ? bl : bh);
-    }
-}
-
-// math mode 2 panels (conv3x3_p16.hip): per panel two 18,432-B halves [s2][tap][hi|lo][lane = h*32 + m][j]; row m is
-// the output channel, the k index of element j is input POSITION 16*s2 + 8h + j of a P16 plane = channel p16_ch(pos).
-__global__ void pack_weights_p16_kernel(const float* params, const PackDesc* descs, unsigned short* fwd, unsigned short* bwd)
-{
-    const PackDesc d = descs[blockIdx.y];
-    const int ns = d.cin / 32, nn = d.cout / 32;
-    const int PE = 2 * PANEL_FLOATS;
-    const long long total = (long long)ns * nn * PE;
-    const float* W = params + d.src_w;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        int r = (int)(e % PE);
-        const int panel = (int)(e / PE);
-        const int j = r & 7; r >>= 3;
-        const int m = r & 31; r >>= 5;
-        const int h = r & 1; r >>= 1;
-        const int part = r & 1; r >>= 1;
-        const int tap = r % 9;
-        const int s2 = r / 9;
-        const int kch = p16_ch(16 * s2 + 8 * h + j);
-        float wf, wb;
-        {
-            const int n = panel / ns, s = panel % ns;
-            const int oc = d.shuffle ? (4 * m + n) : (32 * n + m);
-            wf = W[((long long)oc * d.cin + 32 * s + kch) * 9 + tap];
-        }
-        {
-            const int s = panel / nn, n = panel % nn;
-            const int oc = d.shuffle ? (4 * kch + n) : (32 * n + kch);
-            wb = d.bwd_scale * W[((long long)oc * d.cin + 32 * s + m) * 9 + (8 - tap)];
-        }
-        const __bf16 fh = (__bf16)wf, bh = (__bf16)wb;
-        const __bf16 fl = (__bf16)(wf - (float)fh), bl = (__bf16)(wb - (float)bh);
-        fwd[2 * d.dst_fwd + e] = __builtin_bit_cast(unsigned short, part ? fl : fh);
-        bwd[2 * d.dst_bwd + e] = __builtin_bit_cast(unsigned short, part ? bl : bh);
-    }
-}
-
-// math mode 3 panels (conv3x3_s3.hip, "bf16x6"): fp32 in the fragment order of the bf16 MFMA, [s2][tap][lane = h*32 + m][j]:
+// math mode 3 / 4 panels (conv3x3_s3x.hip "bf16x6"; source of split_panels_f16_kernel for "f16x3"): fp32 in the fragment order of the bf16 MFMA, [s2][tap][lane = h*32 + m][j]:
 // row m is the output channel (input channel for the dgrad panels), the k index of element j is channel 16*s2 + 8h + j of
 // the 32-channel K-chunk.  The conv kernel splits them into three bf16 terms on the way into LDS (streaming 4 B instead of
 // 6 B per weight).  PANEL_FLOATS per panel, like the fp32 panels.
@@ -437,32 +354,6 @@ __global__ void plane_amax_kernel(PlaneIn v, int B, int H, int W, float* slot)
     }
     atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(m));
 }
-#ifdef XSD_EXP_H2
-// math mode 4, experiment XSD_H2: fp32 plane -> "H2" plane, the two fp16 terms of xsd_split.h stored as
-// [pixel][channel half s2][term h | l][16 x f16] (the same 128 B per pixel), scaled with the plane's own max |x|; the scale goes to
-// `hscale` for the consumers (conv3x3_h2x_kernel<true> fetches such planes by LDS-DMA, no conversion in the staging waves).
-__global__ void plane_to_h2_kernel(PlaneIn v, int B, int H, int W, const float* amax, unsigned int* dst, float* hscale)
-{
-    float inv;
-    const float sc = scale_for_amax(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *amax))), inv);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *hscale = sc;
-    const long long total = (long long)B * H * W * 8;        // (pixel, channel quad)
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(g & 7);
-        long long pix = g >> 3;
-        const long long opix = pix;
-        const int x = (int)(pix % W); pix /= W;
-        const int y = (int)(pix % H);
-        const int b = (int)(pix / H);
-        const f32x4 t = *reinterpret_cast<const f32x4*>(v.p + (long long)b * v.bs + (long long)y * v.rs + (long long)x * v.ps + q * 4);
-        split_u32x2 hi, lo;
-        split2_f16x4(t, sc, hi, lo);
-        unsigned int* d = dst + opix * 32 + (q >> 2) * 16 + (q & 3) * 2;      // 32 words per pixel; half s2 = 16 words: h 8 words, l 8 words
-        *reinterpret_cast<split_u32x2*>(d) = hi;
-        *reinterpret_cast<split_u32x2*>(d + 8) = lo;
-    }
-}
-#endif
 __global__ void buffer_amax_kernel(const float* v, long long n, float* slot)
 {
     float m = 0.f;
@@ -487,25 +378,6 @@ __global__ void split_panels_f16_kernel(const float* src, unsigned int* dst, lon
         unsigned int* d = dst + blk * 512 + lane * 4;           // 2 terms x 1 KiB per block = 512 words
         d[0] = ha[0]; d[1] = ha[1]; d[2] = hb[0]; d[3] = hb[1];
         d[256 + 0] = la[0]; d[256 + 1] = la[1]; d[256 + 2] = lb[0]; d[256 + 3] = lb[1];
-    }
-}
-
-// fp32 plane <-> P16 plane (test hooks / debugging): thread = (pixel, 4-channel quad)
-__global__ void plane_to_p16_kernel(const float* in, float* out, long long npix)
-{
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < npix * 8; g += (long long)gridDim.x * blockDim.x) {
-        const long long pix = g >> 3;
-        const int q = (int)(g & 7);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(in + pix * 32 + q * 4);
-        p16_store4(reinterpret_cast<char*>(out + pix * 32), 16 * (q & 1) + 4 * (q >> 1), v);
-    }
-}
-__global__ void plane_from_p16_kernel(const float* in, float* out, long long npix)
-{
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < npix * 8; g += (long long)gridDim.x * blockDim.x) {
-        const long long pix = g >> 3;
-        const int q = (int)(g & 7);
-        *reinterpret_cast<f32x4*>(out + pix * 32 + q * 4) = p16_load4(reinterpret_cast<const char*>(in + pix * 32), 16 * (q & 1) + 4 * (q >> 1));
     }
 }
 
@@ -667,14 +539,12 @@ hipError_t launch_edge_expand(const EdgeExpandParams& p, hipStream_t s)
 hipError_t launch_edge_reduce(const EdgeReduceParams& p, hipStream_t s)
 {
     const long long nblk = (long long)p.B * ((p.W + 31) / 32) * ((p.H + EDGE_BAND - 1) / EDGE_BAND);
-    if (p.p16) hipLaunchKernelGGL(edge_reduce_kernel<true>, dim3((unsigned)(nblk < 8192 ? nblk : 8192)), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(edge_reduce_kernel<false>, dim3((unsigned)(nblk < 8192 ? nblk : 8192)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(edge_reduce_kernel, dim3((unsigned)(nblk < 8192 ? nblk : 8192)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 hipError_t launch_edge_wgrad(const EdgeWgradParams& p, int mode, float* dw, float* db, hipStream_t s)
 {
-    if (p.p16) hipLaunchKernelGGL(edge_wgrad_kernel<true>, dim3(p.nblocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(edge_wgrad_kernel<false>, dim3(p.nblocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(edge_wgrad_kernel, dim3(p.nblocks), dim3(256), 0, s, p);
     hipLaunchKernelGGL(edge_wgrad_final_kernel, dim3(321), dim3(64), 0, s, p.partial, p.nblocks, mode, dw, db);
     return hipGetLastError();
 }
@@ -704,18 +574,6 @@ hipError_t launch_pack_weights(const float* params, const PackDesc* descs_dev, i
     hipLaunchKernelGGL(pack_weights_kernel, dim3(36, ndesc), dim3(256), 0, s, params, descs_dev, fwd, bwd);
     return hipGetLastError();
 }
-hipError_t launch_pack_weights_split(const float* params, const PackDesc* descs_dev, int ndesc, unsigned short* fwd,
-                                     unsigned short* bwd, hipStream_t s)
-{
-    hipLaunchKernelGGL(pack_weights_split_kernel, dim3(72, ndesc), dim3(256), 0, s, params, descs_dev, fwd, bwd);
-    return hipGetLastError();
-}
-hipError_t launch_pack_weights_p16(const float* params, const PackDesc* descs_dev, int ndesc, unsigned short* fwd,
-                                   unsigned short* bwd, hipStream_t s)
-{
-    hipLaunchKernelGGL(pack_weights_p16_kernel, dim3(72, ndesc), dim3(256), 0, s, params, descs_dev, fwd, bwd);
-    return hipGetLastError();
-}
 hipError_t launch_pack_weights_s3(const float* params, const PackDesc* descs_dev, int ndesc, float* fwd, float* bwd,
                                   hipStream_t s)
 {
@@ -727,13 +585,6 @@ hipError_t launch_plane_amax(const PlaneIn& v, int B, int H, int W, float* slot,
     hipLaunchKernelGGL(plane_amax_kernel, dim3(grid_for((long long)B * H * W * 8, 256)), dim3(256), 0, s, v, B, H, W, slot);
     return hipGetLastError();
 }
-#ifdef XSD_EXP_H2
-hipError_t launch_plane_to_h2(const PlaneIn& v, int B, int H, int W, const float* amax, void* dst, float* hscale, hipStream_t s)
-{
-    hipLaunchKernelGGL(plane_to_h2_kernel, dim3(grid_for((long long)B * H * W * 8, 256)), dim3(256), 0, s, v, B, H, W, amax, reinterpret_cast<unsigned int*>(dst), hscale);
-    return hipGetLastError();
-}
-#endif
 hipError_t launch_buffer_amax(const float* v, long long n, float* slot, hipStream_t s)
 {
     hipLaunchKernelGGL(buffer_amax_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, s, v, n, slot);
@@ -743,12 +594,6 @@ hipError_t launch_split_panels_f16(const float* src, void* dst, long long nfloat
 {
     const long long nfrag = nfloats / 8;
     hipLaunchKernelGGL(split_panels_f16_kernel, dim3(grid_for(nfrag, 256)), dim3(256), 0, s, src, reinterpret_cast<unsigned int*>(dst), nfrag, amax);
-    return hipGetLastError();
-}
-hipError_t launch_plane_convert(const float* in, float* out, long long npix, int to_p16, hipStream_t s)
-{
-    if (to_p16) hipLaunchKernelGGL(plane_to_p16_kernel, dim3(grid_for(npix * 8, 256)), dim3(256), 0, s, in, out, npix);
-    else hipLaunchKernelGGL(plane_from_p16_kernel, dim3(grid_for(npix * 8, 256)), dim3(256), 0, s, in, out, npix);
     return hipGetLastError();
 }
 hipError_t launch_pack_edge(const float* w_first, const float* w_last, float* ff, float* fb, float* lf, float* lb,

@@ -34,23 +34,22 @@ constexpr int X3_LT = 64 * X3_LWAVES;               // 256 staging threads
 constexpr int X3_ROWS = 16;
 constexpr int X3_PX = (X3_ROWS + 2) * HALO_W;       // 612 halo pixels
 constexpr int X3_SINK = X3_PX * 32;                 // 19,584: each term image ends with a 512-B sink
-constexpr int X3_XT = 20 * 1024;                    // 20,480 B per term image: twenty 1-KiB LDS-DMA pieces (H2 inputs), sink included
+constexpr int X3_XT = 20 * 1024;                    // 20,480 B per term image (sink included), 1-KiB aligned
 static_assert(X3_XT >= X3_SINK + 512, "sink");
 constexpr int X3_XB = 2 * X3_XT;                    // 40,960 B per input buffer (two term images)
-constexpr int X3_WSINK = H2_WH_BYTES;               // sink behind each weight buffer of the fp32-input variant (2 KiB: the two
-                                                    // LDS-DMA pieces of the last round that have no slots)
-// LDS layout per variant.  fp32 inputs (PIN = false): two input buffers, two weight buffers of 18,432 + 2,048 B (a half-step
-// ends with ONE barrier; the three-term images of mode 3 leave no room for the second).  H2 inputs (PIN = true): THREE input
-// buffers -- the DMA pieces of half-step n+2 are issued while n is multiplied -- and two weight buffers without sink.
-template <bool PIN> struct X3L {
-    static constexpr int NXB = PIN ? 3 : 2;
-    static constexpr int WB = PIN ? H2_WH_BYTES : H2_WH_BYTES + 2048;
-    static constexpr int WOFF = NXB * X3_XB;            // 81,920 / 122,880
-    static constexpr int BIAS = WOFF + 2 * WB;          // 122,880 / 159,744
+constexpr int X3_WSINK = H2_WH_BYTES;               // sink behind each weight buffer (2 KiB: the two LDS-DMA pieces of the last
+                                                    // round that have no slots)
+// LDS layout: two input buffers, two weight buffers of 18,432 + 2,048 B (a half-step ends with ONE barrier; the three-term
+// images of mode 3 leave no room for the second), bias, descriptors.
+struct X3L {
+    static constexpr int NXB = 2;
+    static constexpr int WB = H2_WH_BYTES + 2048;
+    static constexpr int WOFF = NXB * X3_XB;            // 81,920
+    static constexpr int BIAS = WOFF + 2 * WB;          // 122,880
     static constexpr int DESC = BIAS + 5 * 32 * 4;
-    static constexpr int BYTES = DESC + 16 * 8;         // 123,648 / 160,512
+    static constexpr int BYTES = DESC + 16 * 8;         // 123,648
 };
-static_assert(X3L<true>::BYTES <= 160 * 1024 && X3L<false>::BYTES <= 160 * 1024, "LDS");
+static_assert(X3L::BYTES <= 160 * 1024, "LDS");
 constexpr int X3_ROWB = HALO_W * 32;                // 1088
 constexpr int X3_XSLOTS = X3_PX * 4;                // 2448 float4 slots of an input half-tile
 constexpr int X3_XR = (X3_XSLOTS + X3_LT - 1) / X3_LT;     // 10
@@ -59,13 +58,10 @@ constexpr int X3_WR = (X3_WSLOTS + X3_LT - 1) / X3_LT;     // 5 LDS-DMA pieces p
 
 __device__ __forceinline__ void x3_split4(const f32x4& a, float s, u32x2& hi, u32x2& lo) { split2_f16x4(a, s, hi, lo); }   // xsd_split.h
 
-// PIN: every input plane has a pre-split H2 copy (experiment XSD_H2; ConvParams::in_h2 / hscale) -- the staging waves then
-// only issue LDS-DMA pieces, and the MFMA waves rescale their accumulators when the K-loop moves to a plane with another scale
-template <bool PIN>
 __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef X3L<PIN> L;
+    typedef X3L L;
     char* w_lds = smem + L::WOFF;
 
     const int tid = threadIdx.x;
@@ -105,8 +101,8 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
     // plane / panel descriptors and the bias through LDS
     unsigned long long* desc = reinterpret_cast<unsigned long long*>(smem + L::DESC);
     if (tid < 5) {
-        desc[2 * tid] = PIN ? reinterpret_cast<unsigned long long>(P.in_h2[tid]) : reinterpret_cast<unsigned long long>(P.in[tid].p);
-        desc[2 * tid + 1] = PIN ? (unsigned long long)P.H * P.W * 128ull : (unsigned long long)P.in[tid].bs * 4ull;
+        desc[2 * tid] = reinterpret_cast<unsigned long long>(P.in[tid].p);
+        desc[2 * tid + 1] = (unsigned long long)P.in[tid].bs * 4ull;
         desc[10 + tid] = reinterpret_cast<unsigned long long>(P.wstep[tid]);
     }
     float* bias_lds = reinterpret_cast<float*>(smem + L::BIAS);
@@ -124,15 +120,6 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
     // operand scales (powers of two) from the max |x| of the input planes and of the weight panels; every wave computes the
     // same values from the same slots (scalar loads)
     float sx, sw, inv_sx, inv_sw;
-    int he[5] = {127, 127, 127, 127, 127};       // PIN: biased exponent of the (power-of-two) scale each input plane was split
-    if constexpr (PIN) {                         // with -- kept as wave-uniform integers so that everything derived stays scalar
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const float* hp = P.hscale[i];
-            const float a = (i < n_in && hp) ? *hp : 1.f;
-            he[i] = (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a)) >> 23) & 0xff;
-        }
-    }
     {
         float ax = 0.f;
 #pragma unroll
@@ -145,13 +132,6 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
         ax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ax)));
         sx = scale_for_amax(ax, inv_sx);
         sw = scale_for_amax(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, aw))), inv_sw);
-    }
-    if constexpr (PIN) {      // the accumulators start in units of plane 0's scale and end in those of the last plane's
-        sx = __builtin_bit_cast(float, he[0] << 23);
-        int last = he[0];
-#pragma unroll
-        for (int i = 1; i < 5; ++i) last = (i < n_in) ? he[i] : last;
-        inv_sx = __builtin_bit_cast(float, (254 - last) << 23);
     }
     const float inv_s = inv_sx * inv_sw;      // undoes both scales in the epilogue (exact)
 
@@ -187,92 +167,10 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
             const int voff = 16 * (int)__builtin_amdgcn_mbcnt_hi(all, __builtin_amdgcn_mbcnt_lo(all, 0u));
             const int soff = r * (X3_LT * 16) + wid * 1024;
             const bool live = (r + 1) * X3_LT <= X3_WSLOTS || r * X3_LT + wid * 64 < X3_WSLOTS;     // wave-uniform
-            if (PIN && !live) return;     // (the H2 variant's waits do not count pieces: no sink needed)
             const unsigned int dst = lds0 + L::WOFF + wb + (live ? soff : X3_WSINK + (wid & 1) * 1024);
             asm volatile("s_mov_b32 m0, %[l]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[o], %[r], %[s] offen lds"
                          :: [o] "v"(voff), [r] "s"(rs), [s] "s"(soff), [l] "s"(dst) : "memory");
         };
-        if constexpr (PIN) {
-            // ---- inputs as H2 planes: a pass of the loop issues LDS-DMA pieces only.  No register loads, no VALU per byte.
-            // The input image of this variant is ONE image [halo pixel][4 x 16 B] = (h | l) x (channel octet 0 | 1) of the
-            // half-step's 16 channels -- 64 B per pixel, as the 64 B lie in the H2 plane, so that a piece reads 64 contiguous
-            // bytes of 16 lines (two separate term images would read 32 B of 32 lines per piece: measured 10 % SLOWER than
-            // the register path).  Slot i = r*256 + lt (r = 0..9): pixel i >> 2; LDS slot i & 3 holds source slot
-            // (i & 3) ^ f(hx), f = 2 * ((hx >> 2) & 1) + ((hx >> 3) & 1) (source slot = 2 * term + octet): the swizzle lives in the SOURCE address and makes
-            // the MFMA waves' ds_read_b128 (16 consecutive pixels at a 64-B stride) conflict-free.
-            constexpr int NR = 10;
-            int xo[NR];
-            short hy_[NR], hx_[NR];
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int pp = (r * X3_LT + lt) >> 2;
-                const int hy = pp / HALO_W;
-                hy_[r] = (short)hy; hx_[r] = (short)(pp - hy * HALO_W);
-            }
-            auto tile_offsets = [&](const TileXY& T) {
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const int i = r * X3_LT + lt;
-                    const int gy = T.y0 - 1 + hy_[r], gx = T.x0 - 1 + hx_[r];
-                    const bool ok = (i < 4 * X3_PX) && (gy >= 0) && (gy < P.H) && (gx >= 0) && (gx < P.W);
-                    const int f = (((hx_[r] >> 2) & 1) << 1) | ((hx_[r] >> 3) & 1);
-                    xo[r] = ok ? (gy * P.W + gx) * 128 + (((i & 3) ^ f) << 4) : OOR;
-                }
-            };
-            const unsigned int plane_bytes = (unsigned int)P.H * (unsigned int)P.W * 128u;
-            auto x_rsrc = [&](const Cur& c, const TileXY& T, bool live) {
-                const unsigned long long p = uniform64(desc[2 * c.i]), bs = uniform64(desc[2 * c.i + 1]);
-                return make_rsrc(p + (unsigned long long)T.b * bs + c.s2 * 64, live ? plane_bytes - c.s2 * 64 : 0u);
-            };
-            auto dma_x = [&](int r, const i32x4& rs, int xb) {
-                const unsigned int dst = lds0 + xb + (r * X3_LT + wid * 64) * 16;
-                asm volatile("s_mov_b32 m0, %[l]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[o], %[r], 0 offen lds" :: [o] "v"(xo[r]), [r] "s"(rs), [l] "s"(dst) : "memory");
-            };
-            auto stage_w = [&](const Cur& c, bool live, int wpar) {
-                const i32x4 wrs = w_rsrc(c, live);
-#pragma unroll
-                for (int r = 0; r < X3_WR; ++r) dma_w_round(r, wrs, wpar * L::WB);
-            };
-            auto stage_x = [&](const Cur& c, const TileXY& T, bool live, int xpar) {
-                const i32x4 xrs = x_rsrc(c, T, live);
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    dma_x(r, xrs, xpar * X3_XB);
-#ifdef X3_PACE
-                    __builtin_amdgcn_s_sleep(X3_PACE);    // spread the pieces over the half-step: 64 * X3_PACE cycles apart
-#endif
-                }
-            };
-            // prologue: half-step 0 (weights + input) and the input of half-step 1; a pass of the loop then issues the weights
-            // of half-step it+1 and the input of half-step it+2 -- the ten input pieces are the youngest operations of the
-            // wave, so `vmcnt(10)` retires everything half-step it+1 needs and leaves them in flight across the barrier
-            Cur n1 = {0, 0, 0, 0};
-            TileXY t2 = tile_of(0);
-            int kt = 0;                 // tile ordinal the offsets were computed for
-            tile_offsets(t2);
-            stage_w(n1, true, 0);
-            stage_x(n1, t2, true, 0);
-            n1 = succ(n1);              // half-step 1: same tile
-            Cur n2 = succ(n1);
-            stage_x(n1, t2, items > 1, 1);
-            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            lds_barrier();                                                                     // (P)
-            int xp2 = 2;                // input buffer of half-step it+2
-#pragma unroll 1
-            for (int it = 0; it < items; ++it) {
-                const bool more1 = (it + 1 < items), more2 = (it + 2 < items);
-                stage_w(n1, more1, (it + 1) & 1);
-                if (more2 && n2.k != kt) { kt = n2.k; t2 = tile_of(kt); tile_offsets(t2); }
-                stage_x(n2, t2, more2, xp2);
-                xp2 = xp2 == 2 ? 0 : xp2 + 1;
-                asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-                lds_barrier();                                                                 // end of half-step `it`
-                n1 = n2;
-                n2 = succ(n2);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            return;
-        }
         // Staging slots of this thread: slot(r) = r*256 + lt -> halo pixel p = r*64 + (lt >> 2), channel quad q = lt & 3.
         // Everything per-lane about a slot is computed ahead of the loop and kept in registers: its LDS byte offset (fixed)
         // and its byte offset inside the input plane of the tile being prefetched (rebuilt when the tile changes).  A round
@@ -465,7 +363,6 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
         // fragment base offsets rebuilt per half-step from the lane id (a few VALU): held across the loop they get spilled,
         // and a scratch reload in front of the MFMAs is a vector-memory round trip
         int abase[3];
-        int abase1[3];     // PIN: the l term's slot (the swizzle mixes term and octet: not a constant distance from the h term's)
         // the lane id is recomputed (two mbcnt on a mask hipcc cannot see through) rather than kept in a register across the
         // loop, where it gets spilled
         unsigned int all = ~0u;
@@ -476,11 +373,6 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const int hx = (ln & 31) + dx;
-                if constexpr (PIN) {
-                    const int f = (((hx >> 2) & 1) << 1) | ((hx >> 3) & 1);
-                    abase[dx] = (wv * 2) * (2 * X3_ROWB) + hx * 64 + (((ln >> 5) ^ f) << 4);
-                    abase1[dx] = (wv * 2) * (2 * X3_ROWB) + hx * 64 + (((2 | (ln >> 5)) ^ f) << 4);
-                } else
                 abase[dx] = (wv * 2) * X3_ROWB + hx * 32 + (((ln >> 5) ^ ((hx >> 3) & 1)) << 4);
             }
         }
@@ -490,10 +382,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
         };
         auto load_x = [&](int ir, int dx, f16x8 (&a)[2]) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if constexpr (PIN) a[t] = *reinterpret_cast<const f16x8*>(xc + (t ? abase1[dx] : abase[dx]) + ir * (2 * X3_ROWB));
-                else a[t] = *reinterpret_cast<const f16x8*>(xc + t * X3_XT + abase[dx] + ir * X3_ROWB);
-            }
+            for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const f16x8*>(xc + t * X3_XT + abase[dx] + ir * X3_ROWB);
         };
         auto mac = [&](int r, const f16x8 (&w)[2], const f16x8 (&x)[2]) {
             accx[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], x[1], accx[r], 0, 0, 0);   // Wh * Xl   } weighted 2^-11
@@ -648,18 +537,6 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
         const bool more1 = (it + 1 < items);
         X3_TICK(1);
         if (cur.i == 0 && cur.s2 == 0) init_acc(cur.j);
-        if constexpr (PIN) {
-            if (cur.s2 == 0 && cur.i > 0) {      // the next plane was split with another scale: move the partial sums to its units (exact)
-                int de = 0;
-#pragma unroll
-                for (int i = 1; i < 5; ++i) de = (cur.i == i) ? he[i] - he[i - 1] : de;
-                const float rt = __builtin_bit_cast(float, (127 + de) << 23);
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) { acc[r][k] *= rt; accx[r][k] *= rt; }
-            }
-        }
         compute(smem + xpar * X3_XB, it & 1, pending);
         xpar = (xpar + 1 == L::NXB) ? 0 : xpar + 1;
         pending = false;
@@ -715,43 +592,36 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
 #endif
 }
 
+static PerDevice g_once;
+
 hipError_t launch_conv3x3_h2x(const ConvParams& p, hipStream_t stream)
 {
-    static bool done = false;
-    static int ncu = 256;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2x_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, X3L<false>::BYTES);
-        if (e != hipSuccess) return e;
-#ifdef XSD_EXP_H2
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2x_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, X3L<true>::BYTES);
-        if (e != hipSuccess) return e;
-#endif
-        hipDeviceProp_t prop;
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        done = true;
-    }
+    int ncu = 256;
+    hipError_t e = g_once.once([]() {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2x_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, X3L::BYTES);
+    }, &ncu);
+    if (e != hipSuccess) return e;
     if (p.n_in < 1 || p.n_out < 1 || p.n_in * p.n_out > 5 || !p.zero) return hipErrorInvalidValue;
     // the operand scales come from these slots: an unknown maximum must not silently become "1.0" (fp16 would overflow)
     if (!p.amax_w) return hipErrorInvalidValue;
     for (int j = 0; j < p.n_out; ++j) {      // compact masks: only the combinations the epilogue has variants for
         const OutDesc& o = p.out[j];
         if (o.bits_out && (o.accumulate || o.e1 || o.e2 || o.e3 || o.mask)) return hipErrorInvalidValue;
+        // the deferred stores address the output plane with 32-bit BYTE offsets against a descriptor of H * rs * 4 bytes
+        if ((long long)p.H * o.rs * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     }
-    for (int i = 0; i < p.n_in; ++i) if (!p.amax_in[i]) return hipErrorInvalidValue;
+    for (int i = 0; i < p.n_in; ++i) {
+        if (!p.amax_in[i]) return hipErrorInvalidValue;
+        // the staging waves compute every input's lane offsets and buffer range from in[0]'s strides (32-bit byte offsets)
+        if (p.in[i].rs != p.in[0].rs || p.in[i].ps != p.in[0].ps) return hipErrorInvalidValue;
+    }
+    if ((long long)p.H * p.in[0].rs * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     const int tilesY = (p.H + X3_ROWS - 1) / X3_ROWS;
     const int ntiles = p.B * p.tilesX * tilesY;
     if (ntiles <= 0) return hipSuccess;
     const dim3 g(ntiles < ncu ? ntiles : ncu), b(X3_THREADS);
-#ifdef XSD_EXP_H2   // experiment build only (tools/h2_gate.sh): the H2-input variant exists in no production library
-    bool pin = true;          // every input has a pre-split copy (standard layout: 32-bit offsets inside a batch slice)
-    for (int i = 0; i < p.n_in; ++i) pin = pin && p.in_h2[i] && p.hscale[i];
-    if (pin && (long long)p.H * p.W * 128 >= (1ll << 31)) pin = false;
-    if (pin) { hipLaunchKernelGGL(conv3x3_h2x_kernel<true>, g, b, X3L<true>::BYTES, stream, p); return hipGetLastError(); }
-#endif
-    hipLaunchKernelGGL(conv3x3_h2x_kernel<false>, g, b, X3L<false>::BYTES, stream, p);
+    hipLaunchKernelGGL(conv3x3_h2x_kernel, g, b, X3L::BYTES, stream, p);
     return hipGetLastError();
 }
 

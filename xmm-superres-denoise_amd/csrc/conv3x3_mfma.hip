@@ -13,15 +13,6 @@
 // K-steps are software pipelined through registers (issue the next plane's global loads before the MFMAs of the
 // current one, write LDS after the barrier); the second co-resident workgroup covers the short write phase.
 //
-// Two math modes share the structure (template parameter SPLIT):
-//   SPLIT=false : exact fp32, v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD = the fp32 vector rate).
-//   SPLIT=true  : "bf16x3": each fp32 operand is split x = hi + lo (two bf16, 16 significant bits) and the product is
-//                 evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 3 MFMAs at 16x
-//                 the fp32 rate = 5.3x the fp32-MFMA ceiling, per-product error <= 3*2^-16 (measured whole-net error
-//                 5e-6 of max vs the reference, tolerance 1e-3).  Activations stay fp32 in HBM; the split happens once
-//                 per staged element on the way into LDS (pixel row = [32 x hi][32 x lo] bf16 = the same 128 B);
-//                 weights are pre-split by pack_weights_split_kernel into [tap][kstep][hi|lo][lane][8] fragments.
-//
 // Two step structures share the code:
 //   MULTI_OUT=false : n_in input planes (K-loop), one output chunk          (forward dense convs; dgrad of 32->128)
 //   MULTI_OUT=true  : one input plane staged once, n_out output chunks      (dgrad of dense convs; forward 32->128)
@@ -33,28 +24,10 @@ namespace xsd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int IN_SLOTS = HALO_PX * 8;              // 2720 16-byte chunks
 constexpr int IN_ROUNDS = (IN_SLOTS + 255) / 256;  // 11
 constexpr int W_ROUNDS = PANEL_FLOATS / 4 / 256;   // 9
-constexpr int SP_SLOTS = HALO_PX * 4;              // split mode: 1360 (pixel, 8-channel octet) slots of 32 B
-constexpr int SP_ROUNDS = (SP_SLOTS + 255) / 256;  // 6
-
-// fp32 -> (hi, lo) bf16 pair, round-to-nearest-even on both terms
-__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u16x8& hi, u16x8& lo)
-{
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float x = i < 4 ? a[i] : b[i - 4];
-        const __bf16 h = (__bf16)x;
-        const float hf = (float)h;
-        const __bf16 l = (__bf16)(x - hf);
-        hi[i] = __builtin_bit_cast(unsigned short, h);
-        lo[i] = __builtin_bit_cast(unsigned short, l);
-    }
-}
 
 constexpr int CONV_LDS_TOTAL = CONV_LDS_BYTES + 5 * 32 * 4; // + bias -> 81,024 B, still 2 workgroups per CU
 constexpr int ROW_BYTES = HALO_W * 128; // 4352 = 17 x 256: every halo row starts on a bank-row boundary
@@ -65,7 +38,7 @@ constexpr int ROW_BYTES = HALO_W * 128; // 4352 = 17 x 256: every halo row start
 // touches 16 distinct 16-B slots of the 256-B bank row -> conflict-free.
 __device__ __forceinline__ int swz_off(int hy, int hx, int c) { return hy * ROW_BYTES + hx * 128 + ((c ^ ((hx >> 1) & 7)) << 4); }
 
-template <bool MULTI_OUT, bool SPLIT>
+template <bool MULTI_OUT>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -105,76 +78,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int c = SPLIT ? ((k >> 1) * 4 + 2 * (k & 1) + h) : (4 * h + k); // split: k = part*2 + s2
-            abase[dx][k] = swz_off(wv * 2, l31 + dx, c);
+            abase[dx][k] = swz_off(wv * 2, l31 + dx, 4 * h + k);
         }
 
-    f32x4 pin[SPLIT ? 2 * SP_ROUNDS : IN_ROUNDS];
+    f32x4 pin[IN_ROUNDS];
     f32x4 pw[W_ROUNDS];
 
-    // per-thread element offsets of this thread's staging slots inside one image of the current/next tile
-    // (-1 = zero padding / out of range); identical for every plane of the tile, so computed once per tile.
-    constexpr int NR = SPLIT ? SP_ROUNDS : IN_ROUNDS;
+    // per-thread element offset of staging slot r inside one image of the tile (-1 = zero padding / out of range)
     auto slot_offset = [&](int r, const TileXY& T, int rs, int ps) {
         const int slot = r * 256 + tid;
-        const int p = SPLIT ? (slot >> 2) : (slot >> 3);
-        const int sub = SPLIT ? (slot & 3) * 8 : (slot & 7) * 4;
+        const int p = slot >> 3;
+        const int sub = (slot & 7) * 4;
         const int hy = p / HALO_W, hx = p - hy * HALO_W;
         const int gy = T.y0 - 1 + hy, gx = T.x0 - 1 + hx;
-        const bool ok = (slot < (SPLIT ? SP_SLOTS : IN_SLOTS)) && (gy >= 0) && (gy < P.H) && (gx >= 0) && (gx < P.W);
+        const bool ok = (slot < IN_SLOTS) && (gy >= 0) && (gy < P.H) && (gx >= 0) && (gx < P.W);
         return (ok && !(abl & 1)) ? gy * rs + gx * ps + sub : -1;
-    };
-    int goff[SPLIT ? NR : 1]; // split mode keeps the 6 offsets in registers; fp32 mode (11 slots) recomputes them
-    auto tile_offsets = [&](const TileXY& T, int rs, int ps) {
-        if constexpr (SPLIT) {
-#pragma unroll
-            for (int r = 0; r < NR; ++r) goff[r] = slot_offset(r, T, rs, ps);
-        }
     };
     auto load_in = [&](int s, const TileXY& T) {
         const PlaneIn pl = P.in[s];
         const float* base = pl.p + (long long)T.b * pl.bs;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            if constexpr (!SPLIT) {
-                const int off = slot_offset(r, T, pl.rs, pl.ps);
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (off >= 0) v = *reinterpret_cast<const f32x4*>(base + off);
-                pin[r] = v;
-            } else {
-                f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-                if (goff[r] >= 0) {
-                    const f32x4* src = reinterpret_cast<const f32x4*>(base + goff[r]);
-                    v0 = src[0];
-                    v1 = src[1];
-                }
-                pin[2 * r] = v0;
-                pin[2 * r + 1] = v1;
-            }
+        for (int r = 0; r < IN_ROUNDS; ++r) {
+            const int off = slot_offset(r, T, pl.rs, pl.ps);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (off >= 0) v = *reinterpret_cast<const f32x4*>(base + off);
+            pin[r] = v;
         }
     };
     auto store_in = [&]() {
-        if constexpr (!SPLIT) {
 #pragma unroll
-            for (int r = 0; r < IN_ROUNDS; ++r) {
-                const int slot = r * 256 + tid;
-                const int p = slot >> 3, c = slot & 7;
-                const int hy = p / HALO_W, hx = p - hy * HALO_W;
-                if (slot < IN_SLOTS) *reinterpret_cast<f32x4*>(in_lds + swz_off(hy, hx, c)) = pin[r];
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < SP_ROUNDS; ++r) {
-                const int slot = r * 256 + tid;
-                const int p = slot >> 2, o = slot & 3;
-                const int hy = p / HALO_W, hx = p - hy * HALO_W;
-                if (slot < SP_SLOTS) {
-                    u16x8 hi, lo;
-                    split8(pin[2 * r], pin[2 * r + 1], hi, lo);
-                    *reinterpret_cast<u16x8*>(in_lds + swz_off(hy, hx, o)) = hi;       // channels 8o..8o+7, hi terms
-                    *reinterpret_cast<u16x8*>(in_lds + swz_off(hy, hx, 4 + o)) = lo;   // same channels, lo terms
-                }
-            }
+        for (int r = 0; r < IN_ROUNDS; ++r) {
+            const int slot = r * 256 + tid;
+            const int p = slot >> 3, c = slot & 7;
+            const int hy = p / HALO_W, hx = p - hy * HALO_W;
+            if (slot < IN_SLOTS) *reinterpret_cast<f32x4*>(in_lds + swz_off(hy, hx, c)) = pin[r];
         }
     };
     auto load_w = [&](int s) {
@@ -205,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
     };
 
     const char* wl = w_lds + lane * 16;
-    auto compute = [&]() { if (!(abl & 8)) conv_compute<SPLIT, ROW_BYTES>(in_lds, wl, abase, acc); };
+    auto compute = [&]() { if (!(abl & 8)) conv_compute<ROW_BYTES>(in_lds, wl, abase, acc); };
 
     // Epilogue: each lane owns one pixel and 16 channels as four float4 groups -> 16-B loads/stores; lanes l and l+32
     // cover adjacent 16-B chunks, so every store instruction writes 32 x 32 contiguous bytes.
@@ -263,7 +200,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
     if (stamp) t0 = __builtin_readcyclecounter();
     // ---- prologue: stage item 0
     TileXY cur = tile_of(0);
-    tile_offsets(cur, P.in[0].rs, P.in[0].ps);
     load_in(0, cur);
     load_w(0);
     store_in();
@@ -278,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
         const int s_next = (s + 1 == nsteps) ? 0 : s + 1;
         TileXY nxt = cur;
         if (more) {
-            if (s_next == 0) { nxt = tile_of(k + 1); tile_offsets(nxt, P.in[0].rs, P.in[0].ps); }
+            if (s_next == 0) nxt = tile_of(k + 1);
             if (!MULTI_OUT || s_next == 0) load_in(MULTI_OUT ? 0 : s_next, nxt);
             load_w(s_next);
         }
@@ -307,59 +243,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvParams P
     }
 }
 
-template <bool M, bool S>
-static hipError_t set_lds()
-{
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<M, S>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_TOTAL);
-}
-static hipError_t set_lds_once()
-{
-    static bool done = false;
-    if (done) return hipSuccess;
-    hipError_t e;
-    if ((e = set_lds<false, false>()) != hipSuccess) return e;
-    if ((e = set_lds<true, false>()) != hipSuccess) return e;
-    if ((e = set_lds<false, true>()) != hipSuccess) return e;
-    if ((e = set_lds<true, true>()) != hipSuccess) return e;
-    done = true;
-    return hipSuccess;
-}
+static PerDevice g_once;
 
-// split != 0 selects the bf16x3 math mode; p.wpanel must then point at panels written by pack_weights_split_kernel
-hipError_t launch_conv3x3_mfma(const ConvParams& p, int split, hipStream_t stream)
+hipError_t launch_conv3x3_mfma(const ConvParams& p, hipStream_t stream)
 {
-    hipError_t e = set_lds_once();
+    int ncu = 256;
+    hipError_t e = g_once.once([]() {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_TOTAL);
+        if (e1 != hipSuccess) return e1;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_TOTAL);
+    }, &ncu);
     if (e != hipSuccess) return e;
+    if (p.n_in < 1 || p.n_out < 1 || p.n_in * p.n_out > 5) return hipErrorInvalidValue;
     const int ntiles = p.B * p.tilesX * p.tilesY;
     if (ntiles <= 0) return hipSuccess;
-    int ncu = 256;
-    {
-        static int cached = 0;
-        if (!cached) { hipDeviceProp_t prop; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached = prop.multiProcessorCount; else cached = 256; }
-        ncu = cached;
-    }
-    static int wgpc = 0;
-    if (!wgpc) { const char* e = getenv("XSD_WGPC"); wgpc = e ? atoi(e) : 2; if (wgpc < 1) wgpc = 2; }
-    const int resident = wgpc * ncu; // 2 workgroups per CU (LDS 81,024 B each)
+    const int resident = 2 * ncu; // 2 workgroups per CU (LDS 81,024 B each)
     const dim3 g(ntiles < resident ? ntiles : resident), b(256);
-    if (p.n_out > 1) {
-        if (split) hipLaunchKernelGGL((conv3x3_mfma_kernel<true, true>), g, b, CONV_LDS_TOTAL, stream, p);
-        else hipLaunchKernelGGL((conv3x3_mfma_kernel<true, false>), g, b, CONV_LDS_TOTAL, stream, p);
-    } else {
-        if (split) hipLaunchKernelGGL((conv3x3_mfma_kernel<false, true>), g, b, CONV_LDS_TOTAL, stream, p);
-        else hipLaunchKernelGGL((conv3x3_mfma_kernel<false, false>), g, b, CONV_LDS_TOTAL, stream, p);
-    }
+    if (p.n_out > 1) hipLaunchKernelGGL((conv3x3_mfma_kernel<true>), g, b, CONV_LDS_TOTAL, stream, p);
+    else hipLaunchKernelGGL((conv3x3_mfma_kernel<false>), g, b, CONV_LDS_TOTAL, stream, p);
     return hipGetLastError();
 }
 
-// diagnostic: occupancy API answer for the split forward kernel at a given dynamic LDS size
+// diagnostic: occupancy API answer for the forward kernel at a given dynamic LDS size
 int debug_conv_occupancy(int lds_bytes)
 {
     int n = -1;
-    if (set_lds_once() != hipSuccess) return -2;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&conv3x3_mfma_kernel<false, true>), 256, lds_bytes) != hipSuccess) return -3;
-    return n;
+    if (g_once.once([]() { return hipSuccess; }, nullptr) != hipSuccess) return -2;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return -2;
+    const hipError_t q = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&conv3x3_mfma_kernel<false>), 256, lds_bytes);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_TOTAL);
+    return q == hipSuccess ? n : -3;
 }
 
 } // namespace xsd

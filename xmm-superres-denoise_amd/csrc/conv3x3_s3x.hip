@@ -533,20 +533,22 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
 #endif
 }
 
+static PerDevice g_once;
+
 hipError_t launch_conv3x3_s3x(const ConvParams& p, hipStream_t stream)
 {
-    static bool done = false;
-    static int ncu = 256;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_s3x_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        hipDeviceProp_t prop;
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        done = true;
-    }
+    int ncu = 256;
+    hipError_t e = g_once.once([]() {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_s3x_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+    }, &ncu);
+    if (e != hipSuccess) return e;
     if (p.n_in < 1 || p.n_out < 1 || p.n_in * p.n_out > 5 || !p.zero) return hipErrorInvalidValue;
+    for (int j = 0; j < p.n_out; ++j)       // deferred stores: 32-bit BYTE offsets against a descriptor of H * rs * 4 bytes
+        if ((long long)p.H * p.out[j].rs * 4 >= (1ll << 31)) return hipErrorInvalidValue;
+    for (int i = 0; i < p.n_in; ++i)        // the staging waves take every input's lane offsets and range from in[0]'s strides
+        if (p.in[i].rs != p.in[0].rs || p.in[i].ps != p.in[0].ps) return hipErrorInvalidValue;
+    if ((long long)p.H * p.in[0].rs * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     const int tilesY = (p.H + X3_ROWS - 1) / X3_ROWS;
     const int ntiles = p.B * p.tilesX * tilesY;
     if (ntiles <= 0) return hipSuccess;

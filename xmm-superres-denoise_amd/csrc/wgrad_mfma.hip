@@ -9,7 +9,6 @@
 // of them; wave w owns row w of each tile (32 pixels = 16 MFMA k-steps of 2 pixels).  Partial sums are written once
 // per workgroup ([nparts][n][j][9][32][32]) and combined in a fixed order by wgrad_reduce_kernel, so the result is
 // bitwise reproducible (no float atomics).
-#include "p16.h"
 #include "xsd_kernels.h"
 
 namespace xsd {
@@ -160,200 +159,6 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_mfma_kernel(const WgradPa
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// bf16x3 variant: the same GEMM (M = ci, N = co, K = pixels) on v_mfma_f32_32x32x16_bf16 with both operands split
-// into hi + lo bf16 terms while staging (X_hi*G_hi + X_hi*G_lo + X_lo*G_hi, fp32 accumulate).  Both MFMA operands
-// need K (= 8 consecutive pixels) contiguous per lane while memory is [pixel][channel], so the LDS images are kept
-// as four planes [pixel][32 x bf16] (64 B per pixel: X_hi, X_lo, G_hi, G_lo) and read with the gfx950 transposing
-// load ds_read_b64_tr_b16: a 16-lane group fetches a 4-pixel x 16-channel block and each lane receives its channel's
-// 4 consecutive pixels.  4 consecutive pixels = 256 contiguous bytes = one full bank row -> conflict-free for every
-// tap shift; a tap is an immediate offset ((dy*34 + dx)*64 B) on one per-lane base address.
-// ---------------------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
-
-constexpr int XH_OFF = 0;
-constexpr int XL_OFF = HALO_PX * 64;             // 21,760
-constexpr int GH_OFF = 2 * HALO_PX * 64;         // 43,520
-constexpr int GL_OFF = GH_OFF + TILE_H * TILE_W * 64; // 59,904  (total 76,288 = WGRAD_LDS_BYTES)
-
-__device__ __forceinline__ void split4(const f32x4& a, u16x4& hi, u16x4& lo)
-{
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const __bf16 h = (__bf16)a[i];
-        const __bf16 l = (__bf16)(a[i] - (float)h);
-        hi[i] = __builtin_bit_cast(unsigned short, h);
-        lo[i] = __builtin_bit_cast(unsigned short, l);
-    }
-}
-
-// 8 consecutive pixels (k = 8h + 0..7) of this lane's channel from a [pixel][32 x bf16] plane
-__device__ __forceinline__ bf16x8 tr_frag(const char* lds_lane_base, int byte_off)
-{
-    typedef __attribute__((address_space(3))) s16x4* lds_p;
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds_lane_base + byte_off));
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds_lane_base + byte_off + 4 * 64));
-    s16x8 r;
-    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
-    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
-    return __builtin_bit_cast(bf16x8, r);
-}
-
-__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_bf16x3_kernel(const WgradParams P)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = tid >> 6; // 0..7 = tile row
-    const int h = lane >> 5;
-    const int l31 = lane & 31;
-
-    const int part = blockIdx.x;
-    const int j = blockIdx.y;  // input plane
-    const int n = blockIdx.z;  // G chunk
-    const PlaneIn xp = P.x[j];
-    const PlaneIn gp = P.g[n];
-    const int ntiles = P.B * P.tilesY * P.tilesX;
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
-    f32x4 bsum = {0.f, 0.f, 0.f, 0.f}; // this thread's 4 channels (tid & 7) of the G tile it stages
-
-    f32x4 px[X_ROUNDS];
-    f32x4 pg[G_ROUNDS];
-
-    auto load_tile = [&](int t) {
-        const int tx = t % P.tilesX;
-        const int t2 = t / P.tilesX;
-        const int ty = t2 % P.tilesY;
-        const int b = t2 / P.tilesY;
-        const int x0 = tx * TILE_W, y0 = ty * TILE_H;
-        const float* xb = xp.p + (long long)b * xp.bs;
-        const float* gb = gp.p + (long long)b * gp.bs;
-#pragma unroll
-        for (int r = 0; r < X_ROUNDS; ++r) {
-            const int slot = r * WG_THREADS + tid;
-            const int p = slot >> 3, c = slot & 7;
-            const int hy = p / HALO_W, hx = p - hy * HALO_W;
-            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-            const bool ok = (slot < X_SLOTS) && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(xb + (long long)gy * xp.rs + gx * xp.ps + c * 4);
-            px[r] = v;
-        }
-#pragma unroll
-        for (int r = 0; r < G_ROUNDS; ++r) {
-            const int slot = r * WG_THREADS + tid;
-            const int p = slot >> 3, c = slot & 7;
-            const int gy = y0 + (p >> 5), gx = x0 + (p & 31);
-            const bool ok = gy < P.H && gx < P.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(gb + (long long)gy * gp.rs + gx * gp.ps + c * 4);
-            pg[r] = v;
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int r = 0; r < X_ROUNDS; ++r) {
-            const int slot = r * WG_THREADS + tid; // = pixel*8 + quad: 8 B per slot in each plane
-            if (slot < X_SLOTS) {
-                u16x4 hi, lo;
-                split4(px[r], hi, lo);
-                *reinterpret_cast<u16x4*>(smem + XH_OFF + slot * 8) = hi;
-                *reinterpret_cast<u16x4*>(smem + XL_OFF + slot * 8) = lo;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < G_ROUNDS; ++r) {
-            const int slot = r * WG_THREADS + tid;
-            u16x4 hi, lo;
-            split4(pg[r], hi, lo);
-            *reinterpret_cast<u16x4*>(smem + GH_OFF + slot * 8) = hi;
-            *reinterpret_cast<u16x4*>(smem + GL_OFF + slot * 8) = lo;
-            bsum += pg[r];
-        }
-    };
-
-    // per-lane base of the transposing reads: lane i of a 16-lane group addresses block row q = i>>2 (pixel) and
-    // columns 4p..4p+3 (p = i&3) of channel group (lane>>4)&1; the lane half h selects pixels +8.
-    const int i16 = lane & 15;
-    const int lane_off = (8 * h + (i16 >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (i16 & 3) * 8;
-    const char* xbase = smem + wv * (HALO_W * 64) + lane_off; // + plane offset + ((dy*34 + dx + 16*mf) * 64)
-    const char* gbase = smem + wv * (TILE_W * 64) + lane_off;
-
-    int t = part;
-    if (t < ntiles) {
-        load_tile(t);
-        store_tile();
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (; t < ntiles; t += P.nparts) {
-        const bool more = (t + P.nparts < ntiles);
-        if (more) load_tile(t + P.nparts);
-        bf16x8 gh[2], gl[2];
-#pragma unroll
-        for (int mf = 0; mf < 2; ++mf) {
-            gh[mf] = tr_frag(gbase, GH_OFF + 16 * mf * 64);
-            gl[mf] = tr_frag(gbase, GL_OFF + 16 * mf * 64);
-        }
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
-#pragma unroll
-            for (int mf = 0; mf < 2; ++mf) {
-                const int off = (dy * HALO_W + dx + 16 * mf) * 64;
-                const bf16x8 xh = tr_frag(xbase, XH_OFF + off);
-                const bf16x8 xl = tr_frag(xbase, XL_OFF + off);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, gh[mf], acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, gl[mf], acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, gh[mf], acc[tap], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-        if (more) store_tile();
-        __syncthreads();
-    }
-
-    // ---- cross-wave reduction through LDS, one tap at a time (8 waves x 4 KiB), then one coalesced store per tap
-    float* red = reinterpret_cast<float*>(smem);
-    float* outp = P.partial + ((((long long)part * P.n_g + n) * P.n_in + j) * 9) * 1024;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ci = (i & 3) + 8 * (i >> 2) + 4 * h;
-            red[wv * 1024 + ci * 32 + l31] = acc[tap][i];
-        }
-        __syncthreads();
-        for (int e = tid; e < 1024; e += WG_THREADS) {
-            float sacc = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) sacc += red[w * 1024 + e];
-            outp[tap * 1024 + e] = sacc;
-        }
-        __syncthreads();
-    }
-    if (j == 0) { // bias gradient: thread tid staged channels 4*(tid&7)..+3 of the G tiles
-#pragma unroll
-        for (int i = 0; i < 4; ++i) red[tid * 4 + i] = bsum[i];
-        __syncthreads();
-        if (tid < 32) {
-            const int q = tid >> 2, i = tid & 3;
-            float sacc = 0.f;
-            for (int w = 0; w < WG_THREADS / 8; ++w) sacc += red[(w * 8 + q) * 4 + i];
-            P.bias_partial[((long long)part * P.n_g + n) * 32 + tid] = sacc;
-        }
-    }
-}
-
 // Fixed-order combination of the per-workgroup partials into the OIHW gradient (state-dict layout).
 // Block = 1024 threads = 16 waves over 256 consecutive elements: wave w sums partials [w*P/16, (w+1)*P/16) with one
 // float4 per lane (1 KiB contiguous per wave-load, 16 loads in flight), then the 16 wave sums are combined in fixed
@@ -395,7 +200,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReducePar
         const int tap = r % 9; r /= 9;
         const int j = r % R.n_in;
         const int n = r / R.n_in;
-        const int cch = R.p16 ? p16_ch(co) : co, ich = R.p16 ? p16_ch(ci) : ci; // P16 kernel: rows/cols are positions
+        const int cch = co, ich = ci;
         const int oc = R.shuffle ? (4 * cch + n) : (32 * n + cch);
         R.dw[((long long)oc * R.cin_total + (32 * j + ich)) * 9 + tap] = (float)(t * (double)R.scale);
     }
@@ -425,28 +230,24 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReducePar
 #pragma unroll
             for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
             const int co = threadIdx.x & 31, n = threadIdx.x >> 5;
-            const int cch = R.p16 ? p16_ch(co) : co;
+            const int cch = co;
             const int oc = R.shuffle ? (4 * cch + n) : (32 * n + cch);
             R.db[oc] = (float)(t * (double)R.scale);
         }
     }
 }
 
-hipError_t launch_wgrad_mfma(const WgradParams& p, int split, hipStream_t stream)
+static PerDevice g_once;
+
+hipError_t launch_wgrad_mfma(const WgradParams& p, hipStream_t stream)
 {
-    static bool done = false;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16x3_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        done = true;
-    }
+    hipError_t e = g_once.once([]() {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BYTES);
+    }, nullptr);
+    if (e != hipSuccess) return e;
     const dim3 g(p.nparts, p.n_in, p.n_g), b(WG_THREADS);
-    if (split) hipLaunchKernelGGL(wgrad_bf16x3_kernel, g, b, WGRAD_LDS_BYTES, stream, p);
-    else hipLaunchKernelGGL(wgrad_mfma_kernel, g, b, WGRAD_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(wgrad_mfma_kernel, g, b, WGRAD_LDS_BYTES, stream, p);
     return hipGetLastError();
 }
 

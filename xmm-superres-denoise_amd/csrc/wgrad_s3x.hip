@@ -340,15 +340,14 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
 
 hipError_t launch_wgrad_s3x(const WgradParams& p, hipStream_t stream)
 {
-    static bool done = false;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_s3x_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        done = true;
-    }
+    static PerDevice once_;
+    hipError_t e = once_.once([]() {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_s3x_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS_BYTES);
+    }, nullptr);
+    if (e != hipSuccess) return e;
     if (p.nparts & 7) return hipErrorInvalidValue;
-    // 32-bit byte offsets inside one batch slice of a plane (buffer loads); xsd_forward rejects larger images as well
+    // 32-bit byte offsets inside one batch slice of a plane (buffer loads); xsd_forward rejects such images with a message
     for (int i = 0; i < p.n_in; ++i) if ((long long)p.H * p.x[i].rs * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     for (int i = 0; i < p.n_g; ++i) if ((long long)p.H * p.g[i].rs * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     const dim3 g(p.nparts * p.n_in * p.n_g), b(V3_THREADS);

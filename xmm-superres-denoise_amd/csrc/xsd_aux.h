@@ -21,8 +21,8 @@ struct MaskPadParams {
     int upsample;              // nearest x s then / s^2 before the pad (ImageUpsample, dataset.py:44-45); 1 = none
 };
 
-hipError_t launch_conv3x3_mfma(const ConvParams& p, int split, hipStream_t stream);
-hipError_t launch_wgrad_mfma(const WgradParams& p, int split, hipStream_t stream);
+hipError_t launch_conv3x3_mfma(const ConvParams& p, hipStream_t stream);
+hipError_t launch_wgrad_mfma(const WgradParams& p, hipStream_t stream);
 hipError_t launch_wgrad_reduce(const WgradReduceParams& r, hipStream_t stream);
 hipError_t launch_edge_expand(const EdgeExpandParams& p, hipStream_t s);
 hipError_t launch_edge_reduce(const EdgeReduceParams& p, hipStream_t s);
@@ -34,25 +34,15 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, long long n
                        float eps, float gscale, hipStream_t s);
 hipError_t launch_pack_weights(const float* params, const PackDesc* descs_dev, int ndesc, float* fwd, float* bwd,
                                hipStream_t s);
-hipError_t launch_pack_weights_split(const float* params, const PackDesc* descs_dev, int ndesc, unsigned short* fwd,
-                                     unsigned short* bwd, hipStream_t s);
-hipError_t launch_pack_weights_p16(const float* params, const PackDesc* descs_dev, int ndesc, unsigned short* fwd,
-                                   unsigned short* bwd, hipStream_t s);
 hipError_t launch_pack_weights_s3(const float* params, const PackDesc* descs_dev, int ndesc, float* fwd, float* bwd,
                                   hipStream_t s);
-hipError_t launch_conv3x3_s3(const ConvParams& p, hipStream_t stream);
 hipError_t launch_conv3x3_s3x(const ConvParams& p, hipStream_t stream);
-hipError_t launch_wgrad_s3(const WgradParams& p, hipStream_t stream);
 hipError_t launch_wgrad_s3x(const WgradParams& p, hipStream_t stream);
 hipError_t launch_wgrad_h2x(const WgradParams& p, hipStream_t stream);
-hipError_t launch_plane_convert(const float* in, float* out, long long npix, int to_p16, hipStream_t s);
 hipError_t launch_plane_amax(const PlaneIn& v, int B, int H, int W, float* slot, hipStream_t s);   // math mode 4
 hipError_t launch_buffer_amax(const float* v, long long n, float* slot, hipStream_t s);
 hipError_t launch_split_panels_f16(const float* src, void* dst, long long nfloats, const float* amax, hipStream_t s);
-hipError_t launch_plane_to_h2(const PlaneIn& v, int B, int H, int W, const float* amax, void* dst, float* hscale, hipStream_t s);   // experiment XSD_H2
 hipError_t launch_conv3x3_h2x(const ConvParams& p, hipStream_t stream);
-hipError_t launch_conv3x3_p16(const ConvParams& p, hipStream_t stream);
-hipError_t launch_wgrad_p16(const WgradParams& p, hipStream_t stream);
 hipError_t launch_pack_edge(const float* w_first, const float* w_last, float* ff, float* fb, float* lf, float* lb,
                             hipStream_t s);
 hipError_t launch_mask_pad_normalize(const MaskPadParams& p, hipStream_t s);

@@ -78,11 +78,10 @@ struct xsd_engine {
     // packed weights
     float* pk_fwd = nullptr;
     float* pk_bwd = nullptr;
-    unsigned short* pk_fwd_s = nullptr; // bf16x3 (hi|lo) panels, same byte size / offsets as pk_fwd / pk_bwd
-    unsigned short* pk_bwd_s = nullptr;
+    unsigned short* pk_fwd_s = nullptr; // split-mode panels (mode 3: fp32 in bf16-MFMA fragment order; mode 4: two-term fp16 images),
+    unsigned short* pk_bwd_s = nullptr; // same byte size / offsets as pk_fwd / pk_bwd
     int chunk = 0;             // diagnostic library only (env XSD_CHUNK): images per dense-block sweep (0 = whole batch)
     int ablate = 0;            // diagnostic library only (env XSD_ABLATE): ablation knobs of the kernels
-    int h2 = 0;                // experiment builds only (-DXSD_EXP_H2, env XSD_H2=1): pre-split copies of the forward planes, fetched by LDS-DMA
     int math = 4;              // include/xsd.h: xsd_set_math (default: f16x3, the faster of the two fp32-class split modes)
     float* pk_edge = nullptr; // first_fwd, first_bwd, last_fwd, last_bwd (288 each)
     float* pk_sbias = nullptr;
@@ -130,43 +129,11 @@ static void take_conv(long long& off, int cout, int cin, long long& w, long long
     b = off; off += cout;
 }
 
-// bf16x6 conv: the default is the role-split kernel (8 MFMA + 4 staging waves, conv3x3_s3x.hip); the build flag
-// XSD_CONV_UNIFIED (A/B builds, `make unified`) selects the 8-wave kernel in which every wave stages and multiplies
-// (conv3x3_s3.hip).  In the diagnostic library ablate bit 20 picks the other one.
-static bool conv_bf16x6_unified(int ablate)
-{
-#ifdef XSD_CONV_UNIFIED
-    return !(ablate & (1 << 20));
-#else
-    return (ablate & (1 << 20)) != 0;
-#endif
-}
-static hipError_t launch_conv_bf16x6(int ablate, const ConvParams& p, hipStream_t s)
-{
-    return conv_bf16x6_unified(ablate) ? launch_conv3x3_s3(p, s) : launch_conv3x3_s3x(p, s);
-}
-
-// bf16x6 weight gradient, same switch: role-split kernel (one workgroup per CU, `nparts` partial sums) or the unified one
-// (two workgroups per CU, 2 x nparts partials).
-static bool wgrad_bf16x6_unified(int ablate)
-{
-#ifdef XSD_CONV_UNIFIED
-    return !(ablate & (1 << 21));
-#else
-    return (ablate & (1 << 21)) != 0;
-#endif
-}
-static int wgrad_bf16x6_parts(int ablate, int nparts) { return wgrad_bf16x6_unified(ablate) ? 2 * nparts : nparts; }
-static hipError_t launch_wgrad_bf16x6(int ablate, const WgradParams& p, hipStream_t s)
-{
-    return wgrad_bf16x6_unified(ablate) ? launch_wgrad_s3(p, s) : launch_wgrad_s3x(p, s);
-}
-// weight gradient of the split modes: mode 4 (f16x3) has its own role-split kernel (one workgroup per CU); diagnostic ablate
-// bit 22 runs mode 3's kernel instead
-static int wgrad_split_parts(int math, int ablate, int nparts) { return (math == 4 && !(ablate & (1 << 22))) ? nparts : wgrad_bf16x6_parts(ablate, nparts); }
+// weight gradient of the split modes: mode 3 (bf16x6) and mode 4 (f16x3) have their own role-split kernels (one workgroup
+// per CU, `nparts` partial sums); diagnostic ablate bit 22 runs mode 3's kernel in mode 4
 static hipError_t launch_wgrad_split(int math, int ablate, const WgradParams& p, hipStream_t s)
 {
-    return (math == 4 && !(ablate & (1 << 22))) ? launch_wgrad_h2x(p, s) : launch_wgrad_bf16x6(ablate, p, s);
+    return (math == 4 && !(ablate & (1 << 22))) ? launch_wgrad_h2x(p, s) : launch_wgrad_s3x(p, s);
 }
 
 static hipError_t prof_launch(xsd_engine* e, int klass, double flop, double bytes, hipStream_t s, const std::function<hipError_t()>& f)
@@ -199,7 +166,7 @@ static hipError_t launch_conv_any(xsd_engine* eng, ConvParams& p, hipStream_t s)
         }
         return launch_conv3x3_h2x(p, s);
     }
-    return eng->math == 3 ? launch_conv_bf16x6(eng->ablate, p, s) : eng->math == 2 ? launch_conv3x3_p16(p, s) : launch_conv3x3_mfma(p, eng->math, s);
+    return eng->math == 3 ? launch_conv3x3_s3x(p, s) : launch_conv3x3_mfma(p, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -216,27 +183,6 @@ struct Builder {
     // a plane_amax launch in front of the first consumer); a view dies when its buffer is handed out again
     typedef std::tuple<uintptr_t, int, int> ViewKey;
     std::map<ViewKey, float*> amax_valid;
-    // experiment XSD_H2: pre-split copy (and the slot of its scale) of a level-0 plane in standard layout
-    std::map<const float*, std::pair<void*, float*>> h2_of;
-    void make_h2(std::vector<Launch>& F, float* plane)
-    {
-#ifdef XSD_EXP_H2
-        if (!e->h2 || e->math != 4) return;
-        std::vector<Launch> pre;
-        const PlaneIn v = std_in(plane, 0);
-        float* am = slot_of(v, H, W, pre);
-        void* dst = alloc(0);
-        float* hs = new_slot();
-        h2_of[plane] = std::make_pair(dst, hs);
-        const int Bv = B, Hv = H, Wv = W;
-        F.push_back([v, Bv, Hv, Wv, am, dst, hs, pre](hipStream_t s) mutable {
-            for (auto& f : pre) { hipError_t err = f(s); if (err != hipSuccess) return err; }
-            return launch_plane_to_h2(v, Bv, Hv, Wv, am, dst, hs, s);
-        });
-#else
-        (void)F; (void)plane;
-#endif
-    }
     Builder(xsd_engine* e_, int B_, int H_, int W_, bool train_, uintptr_t base_)
         : e(e_), B(B_), H(H_), W(W_), train(train_), base(base_), freelist(8) {}
 
@@ -276,7 +222,6 @@ struct Builder {
         if (!freelist[level].empty()) { off = freelist[level].back(); freelist[level].pop_back(); }
         else { off = top; top += plane_bytes(level); if (top > peak) peak = top; }
         if (e->math == 4) invalidate_range(base + off, plane_bytes(level));
-        h2_of.erase(reinterpret_cast<const float*>(base + off));
         return reinterpret_cast<float*>(base + off);
     }
     float* alloc1(int level) // 1-channel image
@@ -366,15 +311,12 @@ struct Builder {
             for (int i = 0; i < p.n_in; ++i) p.amax_in[i] = slot_of(p.in[i], p.H, p.W, pre);
             for (int j = 0; j < p.n_out; ++j) {   // this launch reports its own outputs
                 OutDesc& o = p.out[j];
-                invalidate_range(reinterpret_cast<uintptr_t>(o.p), 1);
+                // every view of the plane this launch writes loses its slot: a shuffled view (shuf_out) is one of four that
+                // interleave over the whole high-resolution plane, so the range is the view's full extent, not its first byte
+                invalidate_range(reinterpret_cast<uintptr_t>(o.p), (size_t)p.B * (size_t)o.bs * sizeof(float));
                 o.amax = new_slot();
                 amax_valid[ViewKey(reinterpret_cast<uintptr_t>(o.p), o.rs, o.ps)] = o.amax;
             }
-        }
-        if (e->h2 && e->math == 4 && p.n_out == 1) {      // experiment XSD_H2: every input has a pre-split copy -> LDS-DMA staging
-            bool all = true;
-            for (int i = 0; i < p.n_in; ++i) all = all && h2_of.count(p.in[i].p) && p.in[i].ps == 32 && p.in[i].rs == p.W * 32 && p.H == H && p.W == W && p.B == B;
-            if (all) for (int i = 0; i < p.n_in; ++i) { p.in_h2[i] = h2_of[p.in[i].p].first; p.hscale[i] = h2_of[p.in[i].p].second; }
         }
         return [eng, p, pre, bias_from_params, bias_off, flop, bytes](hipStream_t s) mutable {
             if (bias_from_params) p.bias = eng->params + bias_off;
@@ -394,7 +336,7 @@ struct Builder {
         memset(&wp, 0, sizeof(wp));
         wp.B = B; wp.H = H << level; wp.W = W << level;
         wp.tilesX = (wp.W + TILE_W - 1) / TILE_W; wp.tilesY = (wp.H + TILE_H - 1) / TILE_H;
-        wp.n_in = (int)xs.size(); wp.n_g = (int)gs.size(); wp.nparts = e->math >= 3 ? wgrad_split_parts(e->math, e->ablate, e->nparts) : e->nparts;
+        wp.n_in = (int)xs.size(); wp.n_g = (int)gs.size(); wp.nparts = e->nparts;
         for (size_t i = 0; i < xs.size(); ++i) wp.x[i] = xs[i];
         for (size_t i = 0; i < gs.size(); ++i) wp.g[i] = gs[i];
         std::vector<Launch> pre;     // math mode 4: reductions for planes nobody has reported yet
@@ -415,8 +357,8 @@ struct Builder {
             wp.partial = eng->wg_partial; wp.bias_partial = eng->wg_bias_partial;
             rp.partial = eng->wg_partial; rp.bias_partial = eng->wg_bias_partial;
             rp.dw = eng->b_grads + w_off; rp.db = eng->b_grads + b_off;
-            wp.zero = eng->zero_page; wp.ablate = eng->ablate; wp.dbg = eng->dbg; rp.p16 = eng->math == 2;
-            hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return eng->math >= 3 ? launch_wgrad_split(eng->math, eng->ablate, wp, s) : eng->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, eng->math, s); });
+            wp.zero = eng->zero_page; wp.ablate = eng->ablate; wp.dbg = eng->dbg;
+            hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return eng->math >= 3 ? launch_wgrad_split(eng->math, eng->ablate, wp, s) : launch_wgrad_mfma(wp, s); });
             if (err != hipSuccess) return err;
             return launch_wgrad_reduce(rp, s);
         });
@@ -434,20 +376,18 @@ struct Builder {
         e->bwd_stages.assign(blocks + 2, {});
 
         struct RdbAct { float* xin; float* xs[4]; float* out; unsigned short* xb[4]; };
-        const bool use_bits = train && e->math == 2; // compact lrelu' masks (conv3x3_p16 epilogue)
-        const bool rdb_bits = train && (e->math == 2 || e->math == 4 || (e->math == 3 && !conv_bf16x6_unified(e->ablate)));   // ... of the dense blocks' activations (role-split conv epilogues too)
+        const bool rdb_bits = train && e->math >= 3;   // compact lrelu' masks of the dense blocks' activations (role-split conv epilogues)
         std::vector<RdbAct> acts(blocks * 3);
         std::vector<float*> rin(blocks + 1);
 
         // ---- forward ------------------------------------------------------------------------------------------
         float* fea = alloc(0);
         { // conv_first (generator_rrdb.py:67)
-            EdgeExpandParams p; memset(&p, 0, sizeof(p)); p.p16 = e->math == 2;
+            EdgeExpandParams p; memset(&p, 0, sizeof(p));
             p.B = B; p.H = H; p.W = W; p.out = fea; p.w = e->pk_edge + 0; p.mslope = 1.f;
             const long long boff = e->first_b;
             F.push_back([eng, p, boff](hipStream_t s) mutable { p.s = eng->b_x; p.bias = eng->params + boff; return launch_edge_expand(p, s); });
         }
-        make_h2(F, fea);
         float* cur = fea;
         for (int i = 0; i < blocks; ++i) {
             rin[i] = cur;
@@ -480,10 +420,8 @@ struct Builder {
                 // (6 x 33.5 MB per 512^2 image) stay in the Infinity Cache between conv_k and conv_{k+1..5}.
                 const int cb = (e->chunk > 0 && e->chunk < B) ? e->chunk : B;
                 for (int b0 = 0; b0 < B; b0 += cb)
-                    for (int c = 0; c < 5; ++c) {
+                    for (int c = 0; c < 5; ++c)
                         F.push_back(conv_launch(slice(rp[c], b0, std::min(cb, B - b0)), true, e->rdb[(i * 3 + r) * 5 + c].b_off));
-                        if (cb == B) make_h2(F, rp[c].out[0].p);
-                    }
                 for (int k = 0; k < 4; ++k) release(a.xs[k], 0);
                 if (r > 0) release(a.xin, 0);
                 cur = a.out;
@@ -504,7 +442,6 @@ struct Builder {
 
         std::vector<float*> U(nup, nullptr);
         float* H1 = nullptr;
-        unsigned short* h1bits = nullptr; // compact lrelu' mask of H1
         float* pre = nullptr;
         const int lo = nup; // output level
         if (sr) {
@@ -524,14 +461,13 @@ struct Builder {
                 ConvParams p = conv_base(lo);
                 p.n_in = 1; p.n_out = 1; p.in[0] = std_in(feat, lo); p.wpanel = fwdp(e->hr.fwd_off);
                 std_out(p.out[0], H1, lo); p.out[0].slope = 0.2f;
-                if (use_bits) { h1bits = reinterpret_cast<unsigned short*>(alloc1(lo)); p.out[0].bits_out = h1bits; }
                 F.push_back(conv_launch(p, true, e->hr.b_off));
             }
             if (nup > 0) release(U[nup - 1], lo); else release(T, 0);
         }
         pre = train ? alloc1(lo) : nullptr;
         { // conv_last (+x for DN) + clamp, clamp (generator_rrdb.py:107-108,132-135; model.py:49)
-            EdgeReduceParams p; memset(&p, 0, sizeof(p)); p.p16 = e->math == 2;
+            EdgeReduceParams p; memset(&p, 0, sizeof(p));
             p.B = B; p.H = H << lo; p.W = W << lo; p.f = sr ? H1 : T; p.w = e->pk_edge + 2 * 288; p.pre = pre; p.clamp01 = 1;
             const long long boff = e->last_b;
             F.push_back([eng, p, boff, sr](hipStream_t s) mutable {
@@ -548,7 +484,7 @@ struct Builder {
             const long long npx = (long long)B * (H << lo) * (W << lo);
             S.push_back([eng, pre, dpre, npx](hipStream_t s) { return launch_clamp_bwd(pre, eng->b_dy, dpre, npx, s); });
             { // conv_last weight grad
-                EdgeWgradParams p; memset(&p, 0, sizeof(p)); p.p16 = e->math == 2;
+                EdgeWgradParams p; memset(&p, 0, sizeof(p));
                 p.B = B; p.H = H << lo; p.W = W << lo; p.f = sr ? H1 : T; p.s = dpre; p.nblocks = EDGE_WGRAD_BLOCKS;
                 const long long wo = e->last_w, bo = e->last_b;
                 S.push_back([eng, p, wo, bo](hipStream_t s) mutable {
@@ -556,14 +492,14 @@ struct Builder {
                 });
             }
             if (!sr) {
-                EdgeExpandParams p; memset(&p, 0, sizeof(p)); p.p16 = e->math == 2;
+                EdgeExpandParams p; memset(&p, 0, sizeof(p));
                 p.B = B; p.H = H; p.W = W; p.s = dpre; p.w = e->pk_edge + 3 * 288; p.out = dT; p.mslope = 1.f;
                 S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
             } else {
                 float* GH = alloc(lo);
                 { // d(H1) masked by lrelu'(0.2)
-                    EdgeExpandParams p; memset(&p, 0, sizeof(p)); p.p16 = e->math == 2;
-                    p.B = B; p.H = H << lo; p.W = W << lo; p.s = dpre; p.w = e->pk_edge + 3 * 288; p.out = GH; p.mask = H1; p.mslope = 0.2f; p.bits = h1bits;
+                    EdgeExpandParams p; memset(&p, 0, sizeof(p));
+                    p.B = B; p.H = H << lo; p.W = W << lo; p.s = dpre; p.w = e->pk_edge + 3 * 288; p.out = GH; p.mask = H1; p.mslope = 0.2f;
                     S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
                 }
                 const float* hr_in = nup > 0 ? U[nup - 1] : T;
@@ -648,13 +584,13 @@ struct Builder {
         { // last stage: conv_first weight grad and (optionally) dx
             std::vector<Launch>& S = e->bwd_stages[blocks + 1];
             float* dFea = dR; // when blocks == 0 this is d(rrdb out) and needs + dT; blocks >= 1 is enforced at create
-            EdgeWgradParams p; memset(&p, 0, sizeof(p)); p.p16 = e->math == 2;
+            EdgeWgradParams p; memset(&p, 0, sizeof(p));
             p.B = B; p.H = H; p.W = W; p.f = dFea; p.nblocks = EDGE_WGRAD_BLOCKS;
             const long long wo = e->first_w, bo = e->first_b;
             S.push_back([eng, p, wo, bo](hipStream_t s) mutable {
                 p.s = eng->b_x; p.partial = eng->edge_partial; return launch_edge_wgrad(p, 0, eng->b_grads + wo, eng->b_grads + bo, s);
             });
-            EdgeReduceParams q; memset(&q, 0, sizeof(q)); q.p16 = e->math == 2;
+            EdgeReduceParams q; memset(&q, 0, sizeof(q));
             q.B = B; q.H = H; q.W = W; q.f = dFea; q.w = e->pk_edge + 1 * 288; q.clamp01 = 0;
             const float* skipg = sr ? nullptr : dpre;
             S.push_back([eng, q, skipg](hipStream_t s) mutable {
@@ -714,10 +650,12 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     if (const char* m = getenv("XSD_ABLATE")) e->ablate = atoi(m);
     if (const char* m = getenv("XSD_CHUNK")) e->chunk = atoi(m);
 #endif
-#ifdef XSD_EXP_H2
-    if (const char* m = getenv("XSD_H2")) e->h2 = atoi(m);
-#endif
-    if (const char* m = getenv("XSD_MATH")) e->math = (strcmp(m, "f16x3") == 0 || strcmp(m, "4") == 0) ? 4 : (strcmp(m, "bf16x6") == 0 || strcmp(m, "3") == 0) ? 3 : (strcmp(m, "bf16x3_p16") == 0 || strcmp(m, "2") == 0) ? 2 : (strcmp(m, "bf16x3") == 0 || strcmp(m, "1") == 0) ? 1 : 0;
+    if (const char* m = getenv("XSD_MATH")) {
+        if (strcmp(m, "f16x3") == 0 || strcmp(m, "4") == 0) e->math = 4;
+        else if (strcmp(m, "bf16x6") == 0 || strcmp(m, "3") == 0) e->math = 3;
+        else if (strcmp(m, "fp32") == 0 || strcmp(m, "0") == 0) e->math = 0;
+        else { delete e; return fail(XSD_ERR_ARG, "XSD_MATH=%s: the math modes are fp32, bf16x6 and f16x3", m); }
+    }
     const int blocks = cfg->num_res_blocks, nup = cfg->kind == XSD_KIND_SR ? cfg->num_upsample : 0;
     long long off = 0, pk = 0, sb = 0;
     take_conv(off, 32, 1, e->first_w, e->first_b);
@@ -766,8 +704,8 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     CK(hipMalloc((void**)&e->pk_sbias, sizeof(float) * (sb ? sb : 1)));
     CK(hipMalloc((void**)&e->descs_dev, sizeof(PackDesc) * descs.size()));
     CK(hipMemcpy(e->descs_dev, descs.data(), sizeof(PackDesc) * descs.size(), hipMemcpyHostToDevice));
-    CK(hipMalloc((void**)&e->wg_partial, sizeof(float) * (size_t)2 * e->nparts * 5 * PANEL_FLOATS));   // up to 2 x nparts partials (mode 3)
-    CK(hipMalloc((void**)&e->wg_bias_partial, sizeof(float) * (size_t)2 * e->nparts * 4 * 32));
+    CK(hipMalloc((void**)&e->wg_partial, sizeof(float) * (size_t)e->nparts * 5 * PANEL_FLOATS));
+    CK(hipMalloc((void**)&e->wg_bias_partial, sizeof(float) * (size_t)e->nparts * 4 * 32));
     CK(hipMalloc((void**)&e->edge_partial, sizeof(float) * EDGE_WGRAD_BLOCKS * 321));
     CK(hipMalloc((void**)&e->loss_partial, sizeof(double) * 1024));
 #undef CK
@@ -790,7 +728,7 @@ int64_t xsd_param_count(const xsd_engine* e) { return e ? e->nparams : 0; }
 
 int xsd_set_math(xsd_engine* e, int mode)
 {
-    if (!e || mode < 0 || mode > 4) return fail(XSD_ERR_ARG, "math mode must be 0 (fp32), 1 (bf16x3), 2 (bf16x3 over P16 planes), 3 (bf16x6, fp32-class) or 4 (f16x3, fp32-class)");
+    if (!e || (mode != 0 && mode != 3 && mode != 4)) return fail(XSD_ERR_ARG, "math mode must be 0 (fp32, exact), 3 (bf16x6) or 4 (f16x3); modes 1 and 2 (16-bit significands) were removed in round 3");
     if (mode != e->math) { e->math = mode; e->packed = false; e->pB = 0; e->ptrain = -1; e->fwd_saved = false; }
     return XSD_OK;
 }
@@ -813,10 +751,6 @@ int xsd_pack_weights(xsd_engine* e, const float* dev_params, void* stream)
     } else if (e->math == 3) {
         HIPCHK(launch_pack_weights_s3(dev_params, e->descs_dev, e->ndesc, reinterpret_cast<float*>(e->pk_fwd_s), reinterpret_cast<float*>(e->pk_bwd_s), s));
     }
-    else if (e->math == 2)
-        HIPCHK(launch_pack_weights_p16(dev_params, e->descs_dev, e->ndesc, e->pk_fwd_s, e->pk_bwd_s, s));
-    else if (e->math == 1)
-        HIPCHK(launch_pack_weights_split(dev_params, e->descs_dev, e->ndesc, e->pk_fwd_s, e->pk_bwd_s, s));
     else
         HIPCHK(launch_pack_weights(dev_params, e->descs_dev, e->ndesc, e->pk_fwd, e->pk_bwd, s));
     HIPCHK(launch_pack_edge(dev_params + e->first_w, dev_params + e->last_w, e->pk_edge, e->pk_edge + 288, e->pk_edge + 576,
@@ -833,6 +767,9 @@ int xsd_forward(xsd_engine* e, const float* dev_x, float* dev_y, int B, int H, i
     if (!e->packed) return fail(XSD_ERR_STATE, "xsd_pack_weights must be called before xsd_forward");
     const int lo = e->cfg.kind == XSD_KIND_SR ? e->cfg.num_upsample : 0;
     if ((long long)(H << lo) * (W << lo) * 32 >= (1ll << 31)) return fail(XSD_ERR_ARG, "image too large for 32-bit in-image offsets");
+    // the split-mode kernels address a plane's batch slice with 32-bit BYTE offsets (buffer loads / stores): 128 B per pixel
+    if (e->math >= 3 && (long long)(H << lo) * (W << lo) * 128 >= (1ll << 31))
+        return fail(XSD_ERR_ARG, "image of %d x %d output pixels is too large for math modes bf16x6 / f16x3 (32-bit byte offsets: fewer than 2^24 pixels per image); use math mode fp32", H << lo, W << lo);
     if ((W << lo) > EDGE_MAX_W) return fail(XSD_ERR_ARG, "output rows wider than %d pixels are not supported", EDGE_MAX_W);
     int rc = ensure_plan(e, B, H, W, save_for_backward != 0);
     if (rc) return rc;
@@ -1056,20 +993,11 @@ static int pack_single(const float* dev_w, int cout, int cin, float** fwd, float
         HIPCHK(hipStreamSynchronize(s));
         hipFree(tf); hipFree(tb);
     } else if (math == 3) HIPCHK(launch_pack_weights_s3(dev_w, dd, 1, *fwd, *bwd, s));
-    else if (math == 2) HIPCHK(launch_pack_weights_p16(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
-    else if (math == 1) HIPCHK(launch_pack_weights_split(dev_w, dd, 1, (unsigned short*)*fwd, (unsigned short*)*bwd, s));
     else HIPCHK(launch_pack_weights(dev_w, dd, 1, *fwd, *bwd, s));
     HIPCHK(hipStreamSynchronize(s));
     hipFree(dd);
     return XSD_OK;
 }
-
-// math mode 2 works on P16 planes: the hooks convert the caller's fp32 planes in and out
-struct TmpPlanes {
-    std::vector<float*> bufs;
-    ~TmpPlanes() { for (float* b : bufs) hipFree(b); }
-    float* make(long long npix) { float* b = nullptr; if (hipMalloc((void**)&b, npix * 128) != hipSuccess) return nullptr; bufs.push_back(b); return b; }
-};
 
 static hipError_t run_conv(xsd_engine* e, ConvParams& p, hipStream_t s)
 {
@@ -1087,9 +1015,8 @@ static hipError_t run_conv(xsd_engine* e, ConvParams& p, hipStream_t s)
         if (!p.amax_w) return hipErrorInvalidValue;   // set by the hook from pack_single's slots (forward or input-gradient panels)
         return launch_conv3x3_h2x(p, s);
     }
-    if (e->math == 3) return launch_conv_bf16x6(e->ablate, p, s);
-    if (e->math == 2) return launch_conv3x3_p16(p, s);
-    return launch_conv3x3_mfma(p, e->math, s);
+    if (e->math == 3) return launch_conv3x3_s3x(p, s);
+    return launch_conv3x3_mfma(p, s);
 }
 
 int xsd_test_conv3x3(xsd_engine* e, const float* const* in_planes, int n_in, const float* dev_w_oihw, const float* dev_bias,
@@ -1100,27 +1027,13 @@ int xsd_test_conv3x3(xsd_engine* e, const float* const* in_planes, int n_in, con
     float *fwd = nullptr, *bwd = nullptr;
     int rc = pack_single(dev_w_oihw, 32 * n_out, 32 * n_in, &fwd, &bwd, e->math, s, e->amax + xsd_engine::AMAX_CAP - 4);
     if (rc) return rc;
-    const long long npix = (long long)B * H * W;
-    TmpPlanes tmp;
-    std::vector<const float*> ins(n_in);
-    std::vector<float*> outs(n_out);
-    for (int i = 0; i < n_in; ++i) {
-        ins[i] = in_planes[i];
-        if (e->math == 2) { float* t = tmp.make(npix); if (!t) return fail(XSD_ERR_NOMEM, "tmp"); launch_plane_convert(in_planes[i], t, npix, 1, s); ins[i] = t; }
-    }
-    for (int j = 0; j < n_out; ++j) {
-        outs[j] = out_planes[j];
-        if (e->math == 2) { float* t = tmp.make(npix); if (!t) return fail(XSD_ERR_NOMEM, "tmp"); outs[j] = t; }
-    }
     Builder b(e, B, H, W, false, 0);
     ConvParams p = b.conv_base(0);
     p.n_in = n_in; p.n_out = n_out; p.wpanel = fwd; p.bias = dev_bias;
     p.amax_w = e->amax + xsd_engine::AMAX_CAP - 4;     // mode 4: max |w| of the forward panels (pack_single)
-    for (int i = 0; i < n_in; ++i) p.in[i] = b.std_in(ins[i], 0);
-    for (int j = 0; j < n_out; ++j) { b.std_out(p.out[j], outs[j], 0); p.out[j].slope = slope; }
+    for (int i = 0; i < n_in; ++i) p.in[i] = b.std_in(in_planes[i], 0);
+    for (int j = 0; j < n_out; ++j) { b.std_out(p.out[j], out_planes[j], 0); p.out[j].slope = slope; }
     hipError_t err = run_conv(e, p, s);
-    if (err == hipSuccess && e->math == 2)
-        for (int j = 0; j < n_out; ++j) launch_plane_convert(outs[j], out_planes[j], npix, 0, s);
     hipStreamSynchronize(s);
     hipFree(fwd); hipFree(bwd);
     if (err != hipSuccess) return fail(XSD_ERR_HIP, "conv launch: %s", hipGetErrorString(err));
@@ -1135,33 +1048,17 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
     float *fwd = nullptr, *bwd = nullptr;
     int rc = pack_single(dev_w_oihw, 32, 32 * n_in, &fwd, &bwd, e->math, s, e->amax + xsd_engine::AMAX_CAP - 4);
     if (rc) return rc;
-    const long long npix = (long long)B * H * W;
-    TmpPlanes tmp;
-    std::vector<const float*> ins(n_in);
-    std::vector<float*> dxs(n_in);
     const float* g = dev_g_plane;
-    if (e->math == 2) {
-        float* t = tmp.make(npix); if (!t) return fail(XSD_ERR_NOMEM, "tmp");
-        launch_plane_convert(dev_g_plane, t, npix, 1, s); g = t;
-    }
-    for (int i = 0; i < n_in; ++i) {
-        ins[i] = in_planes[i]; dxs[i] = dx_planes[i];
-        if (e->math == 2) {
-            float* t = tmp.make(npix); float* u = tmp.make(npix);
-            if (!t || !u) return fail(XSD_ERR_NOMEM, "tmp");
-            launch_plane_convert(in_planes[i], t, npix, 1, s); ins[i] = t; dxs[i] = u;
-        }
-    }
     Builder b(e, B, H, W, false, 0);
     ConvParams p = b.conv_base(0);
     p.n_in = 1; p.n_out = n_in; p.wpanel = bwd; p.in[0] = b.std_in(g, 0);
     p.amax_w = e->amax + xsd_engine::AMAX_CAP - 3;     // mode 4: max |w| of the input-gradient panels
-    for (int j = 0; j < n_in; ++j) b.std_out(p.out[j], dxs[j], 0);
+    for (int j = 0; j < n_in; ++j) b.std_out(p.out[j], dx_planes[j], 0);
     hipError_t err = run_conv(e, p, s);
     if (err == hipSuccess) {
         WgradParams wp; memset(&wp, 0, sizeof(wp));
-        wp.B = B; wp.H = H; wp.W = W; wp.tilesX = p.tilesX; wp.tilesY = p.tilesY; wp.n_in = n_in; wp.n_g = 1; wp.nparts = e->math >= 3 ? wgrad_split_parts(e->math, e->ablate, e->nparts) : e->nparts;
-        for (int i = 0; i < n_in; ++i) wp.x[i] = b.std_in(ins[i], 0);
+        wp.B = B; wp.H = H; wp.W = W; wp.tilesX = p.tilesX; wp.tilesY = p.tilesY; wp.n_in = n_in; wp.n_g = 1; wp.nparts = e->nparts;
+        for (int i = 0; i < n_in; ++i) wp.x[i] = b.std_in(in_planes[i], 0);
         wp.g[0] = b.std_in(g, 0);
         wp.partial = e->wg_partial; wp.bias_partial = e->wg_bias_partial; wp.zero = e->zero_page;
         if (e->math == 4) {   // test hook: reduce the operands' max |x| here (slots at the end of the array, after run_conv's)
@@ -1171,17 +1068,14 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
             if (err == hipSuccess) { err = launch_plane_amax(wp.g[0], B, H, W, t + 5, s); wp.amax_g[0] = t + 5; }
         }
         if (err == hipSuccess)
-            err = e->math >= 3 ? launch_wgrad_split(e->math, e->ablate, wp, s) : e->math == 2 ? launch_wgrad_p16(wp, s) : launch_wgrad_mfma(wp, e->math, s);
+            err = e->math >= 3 ? launch_wgrad_split(e->math, e->ablate, wp, s) : launch_wgrad_mfma(wp, s);
         if (err == hipSuccess) {
             WgradReduceParams rp; memset(&rp, 0, sizeof(rp));
             rp.partial = e->wg_partial; rp.bias_partial = e->wg_bias_partial; rp.nparts = wp.nparts; rp.n_in = n_in; rp.n_g = 1;
             rp.cin_total = 32 * n_in; rp.cout_total = 32; rp.shuffle = 0; rp.scale = 1.f; rp.dw = dev_dw_oihw; rp.db = dev_db;
-            rp.p16 = e->math == 2;
             err = launch_wgrad_reduce(rp, s);
         }
     }
-    if (err == hipSuccess && e->math == 2)
-        for (int j = 0; j < n_in; ++j) launch_plane_convert(dxs[j], dx_planes[j], npix, 0, s);
     hipStreamSynchronize(s);
     hipFree(fwd); hipFree(bwd);
     if (err != hipSuccess) return fail(XSD_ERR_HIP, "bwd launch: %s", hipGetErrorString(err));

@@ -7,7 +7,36 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 namespace xsd {
+
+// One-time per-DEVICE setup of a launcher (hipFuncSetAttribute of the dynamic LDS size is per device; so is the CU count):
+// keyed by the current device id, serialised by a mutex, so a process that drives several GPUs, or several host threads,
+// gets the attribute set and the right grid size on each of them.
+struct PerDevice {
+    static constexpr int MAXDEV = 64;
+    std::mutex mu;
+    bool done[MAXDEV] = {};
+    int ncu[MAXDEV] = {};
+    template <class F> hipError_t once(F&& setup, int* ncu_out)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= MAXDEV) return hipErrorInvalidDevice;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!done[dev]) {
+            if ((e = setup()) != hipSuccess) return e;
+            hipDeviceProp_t prop;
+            if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+            ncu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            done[dev] = true;
+        }
+        if (ncu_out) *ncu_out = ncu[dev];
+        return hipSuccess;
+    }
+};
 
 constexpr int TILE_H = 8;          // output rows per workgroup
 constexpr int TILE_W = 32;         // output cols per workgroup (= MFMA M)
@@ -45,8 +74,8 @@ struct OutDesc {
     const float* mask;
     float a1, s1, a2, s2, s3, slope, mslope;
     int accumulate;
-    // Compact lrelu' masks (math mode 2, training): bit i of the 16-bit word [pixel][lane half h] says whether the stored
-    // value at P16 position 16h + i is > 0.  A conv that produces an activation writes them (bits_out, 4 B per pixel);
+    // Compact lrelu' masks (split math modes, training): bit 4q + t of the 16-bit word [pixel][lane half h] says whether the
+    // stored value of channel 8q + 4h + t is > 0.  A conv that produces an activation writes them (bits_out, 4 B per pixel);
     // the input-gradient conv masked by that activation reads them (bits_in) instead of the 128 B-per-pixel plane.
     unsigned short* bits_out;
     const unsigned short* bits_in;
@@ -71,16 +100,12 @@ struct ConvParams {
                          // L2-resident 64 KiB window per workgroup; conv3x3_p16: 16384 tap-major MFMA loop instead of the
                          // row-reuse loop; wgrad_p16: 4096 G tile requested once per workgroup
     int pad_;
-    const void* zero;    // >= 64 B of zeros in HBM (math mode 2: DMA source for zero padding)
+    const void* zero;    // 256 B of zeros + 256 B of trash in HBM (epilogue operand loads / stores of lanes outside the image)
     unsigned long long* dbg; // diagnostic phase stamps (null in production): [grid][8] accumulated shader cycles
     // math mode 4 (f16x3): max |x| of each input plane and of the weight panels of this launch (device slots written by
     // the producers, read at kernel start); the kernel scales both operands by powers of two into the fp16 range
     const float* amax_in[5];
     const float* amax_w;
-    // experiment XSD_H2: pre-split copies of the input planes ([pixel][s2][h | l][16 x f16], standard layout) and the scale
-    // each was split with; when every input has one the kernel fetches them by LDS-DMA
-    const void* in_h2[5];
-    const float* hscale[5];
     OutDesc out[5];
 };
 
@@ -94,7 +119,7 @@ struct WgradParams {
     PlaneIn g[4];
     float* partial;      // [nparts][n_g][n_in][9][32 ci][32 co]
     float* bias_partial; // [nparts][n_g][32]
-    const void* zero;    // zero page (P16 kernel)
+    const void* zero;    // zero page
     int ablate;          // diagnostic (env XSD_ABLATE): 4096 = request the G tile only for the first tile of a workgroup
     int pad_;
     unsigned long long* dbg; // diagnostic phase stamps (null in production): slots [8..15] of the engine's stamp buffer
@@ -108,7 +133,6 @@ struct WgradReduceParams {
     int nparts, n_in, n_g;
     int cin_total, cout_total;
     int shuffle;   // 1: output channel oc = 4*co + n (pixel-shuffle conv), else oc = 32*n + co
-    int p16;       // 1: partial rows/cols are P16 positions (p16.h), map back to channels
     float scale;
     float* dw;     // OIHW [cout_total][cin_total][3][3]
     float* db;     // [cout_total]
@@ -133,7 +157,6 @@ struct EdgeExpandParams { // 1 -> 32 conv:  out[p][c] = bias[c] + sum_tap s[p+ta
     float* out;          // [B][H][W][32]
     const float* mask;   // plane or null
     float mslope;
-    int p16;             // planes (out, mask) are P16
     const unsigned short* bits; // compact form of `mask` (OutDesc::bits_out layout) or null
 };
 struct EdgeReduceParams { // 32 -> 1 conv: pre[p] = bias + sum_tap sum_c f[p+tap][c] * w[tap][c] (+ skip[p]); y = clamp(pre)
@@ -146,7 +169,6 @@ struct EdgeReduceParams { // 32 -> 1 conv: pre[p] = bias + sum_tap sum_c f[p+tap
     float* y;            // output
     int clamp01;
     const float* addto;  // y = value + addto[p] (used for dx = dgrad + skip-grad), may be null
-    int p16;             // plane f is P16
 };
 constexpr int EDGE_BAND = 32;     // rows per workgroup of the 32 -> 1 edge conv
 constexpr int EDGE_MAX_W = 4096;  // widest image row the edge kernels stage in LDS
@@ -156,7 +178,6 @@ struct EdgeWgradParams { // out[tap][c] = sum_p f[p][c] * s[p+tap]; bsum[c] = su
     const float* s;
     float* partial;      // [nblocks][9*32 + 32 + 1]
     int nblocks;
-    int p16;             // plane f is P16
 };
 
 } // namespace xsd

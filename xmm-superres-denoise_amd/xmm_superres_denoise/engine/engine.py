@@ -56,13 +56,14 @@ class Engine:
         except Exception:
             pass
 
-    MATH = {"fp32": 0, "bf16x3": 1, "bf16x3_p16": 2, "bf16x6": 3, "f16x3": 4}
+    MATH = {"fp32": 0, "bf16x6": 3, "f16x3": 4}
 
     def set_math(self, mode: str):
-        """'fp32' (exact fp32 MFMA), 'f16x3' (default; fp32-class: 2-term fp16 split of power-of-two-scaled operands, 3
-        products), 'bf16x6' (fp32-class: exact 3-term bf16 split, 6 products, single-rounding MFMA accumulation, fp32
-        planes), 'bf16x3' (2-term split, 16-bit significands, fp32 planes) or 'bf16x3_p16' (2-term
-        split over pre-split P16 planes, LDS-DMA staging); include/xsd.h: xsd_set_math."""
+        """'fp32' (exact fp32 MFMA), 'bf16x6' (strict: exact 3-term bf16 split, 6 products, single-rounding MFMA accumulation)
+        or 'f16x3' (default: 2-term fp16 split of power-of-two-scaled operands, 22-23 significant bits per operand, 3
+        products); fp32 planes in all three.  include/xsd.h: xsd_set_math."""
+        if mode not in self.MATH:
+            raise XsdError(f"unknown math mode {mode!r}: the modes are {sorted(self.MATH)}")
         check(self.L.xsd_set_math(self.h, self.MATH[mode]))
 
     def get_math(self) -> str:

@@ -13,6 +13,21 @@ from torch import nn
 from xmm_superres_denoise.config.config import BaseModels, ModelCfg
 
 
+def _mean_over_ranks(values: dict) -> dict:
+    """`sync_dist=True` semantics of the reference's logging (models/model.py:118,150) for a metric collection that cannot
+    reduce its own states: every rank contributes every key, in sorted order, so the collectives match."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not values:
+        return values
+    keys = sorted(values)
+    t = torch.stack([torch.as_tensor(values[k]).detach().double().reshape(()) for k in keys])
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    t = (t / dist.get_world_size()).float()
+    return {k: t[i] for i, k in enumerate(keys)}
+
+
 class Model(nn.Module):
     def __init__(self, config: ModelCfg, lr_shape: Tuple[int, int], hr_shape: Tuple[int, int], loss=None,
                  metrics=None, extended_metrics=None, in_metrics=None, in_extended_metrics=None):
@@ -120,7 +135,9 @@ class Model(nn.Module):
             if coll is not None:
                 if hasattr(coll, "sync"):
                     coll.sync()
-                logged.update(coll.compute())
+                    logged.update(coll.compute())
+                else:       # a collection without state reduction: fall back to the mean over the ranks of its values
+                    logged.update(_mean_over_ranks(coll.compute()))
                 coll.reset()
                 if name.startswith("in_"):
                     setattr(self, name, None)      # input metrics are only needed once (reference :135-142)

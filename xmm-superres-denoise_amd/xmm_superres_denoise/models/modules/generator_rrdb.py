@@ -183,7 +183,7 @@ class _GeneratorRRDB(nn.Module):
         return self.flatten_parameters()
 
     def set_math(self, mode: str):
-        """Math mode of the conv kernels (Engine.set_math): 'fp32', 'f16x3' and 'bf16x6' (fp32-class splits), 'bf16x3', 'bf16x3_p16'."""
+        """Math mode of the conv kernels (Engine.set_math): 'fp32' (exact), 'bf16x6' (strict split), 'f16x3' (default split)."""
         if mode not in Engine.MATH:
             raise ValueError(mode)
         self._math = mode

@@ -47,11 +47,23 @@ def fit(name: str = "rrdb_denoise", lr_res: int = 416, batch_size: int = 4, step
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device(device or f"cuda:{local_rank}")
+    # one process per GPU over RCCL ("nccl"); XSD_DIST_BACKEND=gloo rehearses N ranks on fewer GPUs (ranks then share devices),
+    # exactly as bench.py does
+    backend = os.environ.get("XSD_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise RuntimeError("train.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    if backend == "nccl" and world > ndev:
+        raise RuntimeError(f"{world} ranks but {ndev} GPU(s): RCCL needs one GPU per rank (XSD_DIST_BACKEND=gloo rehearses the "
+                           "multi-rank path on fewer GPUs)")
+    dev = torch.device(device or f"cuda:{local_rank if backend == 'nccl' else local_rank % ndev}")
     torch.cuda.set_device(dev)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     cfg = model_cfg(name, batch_size=batch_size)
     hr_res = lr_res * (2 if name == "esr_gen" else 1)
     torch.manual_seed(seed)
@@ -105,7 +117,7 @@ def main():
     ap.add_argument("--batch-size", type=int, default=4)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--checkpoint", default=None)
-    ap.add_argument("--math", default=None, choices=[None, "fp32", "bf16x6", "f16x3", "bf16x3", "bf16x3_p16"])
+    ap.add_argument("--math", default=None, choices=[None, "fp32", "bf16x6", "f16x3"])
     ap.add_argument("--loss", default="l1", choices=["l1", "paper"], help="paper = 0.5 psnr + 0.5 ms_ssim (loss_functions.toml)")
     ap.add_argument("--scaling", default="linear", choices=["linear", "sqrt", "asinh", "log"])
     ap.add_argument("--val-batches", type=int, default=0, help="validation batches after training (loss + metric set)")

@@ -78,19 +78,29 @@ class EpochState:
             self.acc = torch.stack([a[0] + cur[0], a[1] + cur[1], torch.minimum(a[2], cur[2]), torch.maximum(a[3], cur[3]),
                                     a[4] + cur[4], a[5] + cur[5], a[6] + cur[6], a[7] + cur[7], a[8] + cur[8]])
 
-    def sync(self, group=None) -> None:
+    def sync(self, group=None, device=None) -> None:
         """Reduce the STATES over the ranks before compute(), as torchmetrics does (dist_reduce_fx: "sum" for the sums and
         counts, "min" / "max" for the target range; reference metrics/metrics.py:16-21): PSNR of the pooled squared error,
-        not a mean of per-rank PSNRs."""
+        not a mean of per-rank PSNRs.  A rank that saw no batch (uneven validation shards) still takes part in every
+        collective, with the identity state -- all zeros: the sums' identity, and the target range starts at [0, 0] on every
+        rank anyway -- so the ranks' collective sequences always match.  If NO rank saw a batch the state stays empty."""
         import torch.distributed as dist
-        if self.acc is None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return
-        a = self.acc.clone()
+        if self.acc is not None:
+            a = self.acc.clone()
+        else:
+            if device is None:
+                device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            a = torch.zeros(9, dtype=torch.float64, device=device)
         sums = a[[0, 1, 4, 5, 6, 7, 8]].contiguous()
         lo, hi = a[2:3].contiguous(), a[3:4].contiguous()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        if float(sums[1]) == 0.0:
+            self.acc = None
+            return
         self.acc = torch.stack([sums[0], sums[1], lo[0], hi[0], sums[2], sums[3], sums[4], sums[5], sums[6]])
 
     def compute(self) -> dict:
