@@ -94,14 +94,25 @@ def test_no_product_import_of_oracle():
                 assert "oracle" not in txt.lower() or f == "README.md", os.path.join(dp, f)
 
 
-def test_constructor_rejects_unsupported_widths_early():
-    """reference constructors take any widths (generator_rrdb.py:10-54); the engine is specialised, and says so at
-    construction instead of at the first forward"""
+def test_constructors_take_any_widths_like_the_reference():
+    """reference constructors take any widths (generator_rrdb.py:10-54; rrdb_blocks.py:23 defaults nf = 64): so do these, with
+    the reference's parameter names and shapes (checked against the names the reference itself produced for the nf = 8
+    goldens); what cannot work is refused at construction, not at the first forward"""
+    import numpy as np
+    import gen_common as gc
     from xmm_superres_denoise import models as M
-    with pytest.raises(ValueError, match="num_filters = 32"):
-        M.GeneratorRRDB_DN(1, 1, 8, 1)
-    with pytest.raises(ValueError, match="in_channels"):
-        M.GeneratorRRDB_SR(3, 1, 32, 1)
+    for kind, name, nup in (("dn", "dn_nf8_b1", 1), ("sr", "sr_nf8_b1", 1), ("sr", "sr_nf8_b1_up2", 2)):
+        z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+        m = M.GeneratorRRDB_DN(1, 1, 8, 1) if kind == "dn" else M.GeneratorRRDB_SR(1, 1, 8, 1, num_upsample=nup)
+        assert [n for n, _ in m.named_parameters()] == [str(n) for n in z["param_names"]]
+        shapes = gc.rrdb_param_shapes(kind, 8, 1, num_upsample=nup)
+        assert {n: tuple(p.shape) for n, p in m.named_parameters()} == dict(shapes)
+    m = M.GeneratorRRDB_SR(3, 2, 64, 2, num_upsample=1)          # the dense block's own default width, RGB in
+    assert m.conv_first.weight.shape == (64, 3, 3, 3) and m.rrdb[1].RDB3.conv5.weight.shape == (64, 320, 3, 3) and m.conv_last.weight.shape == (2, 64, 3, 3)
+    with pytest.raises(ValueError, match="in_channels must equal"):
+        M.GeneratorRRDB_DN(3, 2, 32, 1)                           # `out + x` cannot broadcast (generator_rrdb.py:134)
+    with pytest.raises(ValueError, match="num_filters"):
+        M.GeneratorRRDB_DN(1, 1, 0, 1)
     with pytest.raises(ValueError, match="num_upsample"):
         M.GeneratorRRDB_SR(1, 1, 32, 1, num_upsample=3)
 

@@ -14,7 +14,7 @@ def test_status_codes_and_messages():
     from xmm_superres_denoise.engine._lib import XsdConfig, load
     L = load()
     h = ctypes.c_void_p()
-    for bad in (dict(kind=2), dict(num_filters=16), dict(in_channels=3), dict(num_res_blocks=0), dict(kind=1, num_upsample=3)):
+    for bad in (dict(kind=2), dict(num_filters=0), dict(in_channels=3, out_channels=2), dict(num_res_blocks=0), dict(kind=1, num_upsample=3)):
         cfg = dict(kind=0, in_channels=1, out_channels=1, num_filters=32, num_res_blocks=1, num_upsample=1, memory_efficient=0, reserved=0)
         cfg.update(bad)
         assert L.xsd_create(ctypes.byref(XsdConfig(**cfg)), ctypes.byref(h)) < 0, bad

@@ -109,3 +109,68 @@ def test_l1_loss_kernel(eng):
     assert abs(loss.item() - np.abs(y.astype(np.float64) - t).mean()) < 1e-6
     ref = np.sign(y - t) / y.size
     assert np.allclose(dy.cpu().numpy(), ref, rtol=1e-6, atol=0)
+
+
+def _guarded_planes(n, B, H, W, fill, guard_px=4096):
+    """n planes [B][H][W][32] carved out of ONE allocation with NaN guard bands in front of, between and behind them; returns
+    (planes, check) where check() asserts that every guard element is still NaN (a stray store of any kernel lands there or on a
+    neighbouring plane, which the value checks catch)."""
+    plane = B * H * W * 32
+    g = guard_px * 32
+    buf = torch.full(((n + 1) * g + n * plane,), float("nan"), device="cuda")
+    planes = []
+    for i in range(n):
+        p = buf[(i + 1) * g + i * plane:(i + 1) * g + (i + 1) * plane].view(B, H, W, 32)
+        if fill is not None:
+            p.copy_(fill[i])
+        planes.append(p)
+
+    def check():
+        for i in range(n + 1):
+            band = buf[i * (g + plane):i * (g + plane) + g]
+            assert bool(torch.isnan(band).all()), f"guard band {i} was written"
+    return planes, check
+
+
+@pytest.mark.parametrize("n_in", [1, 3, 5])
+def test_full_grid_dispatch_with_guard_bands(eng, n_in):
+    """The dispatch shape of the round-2 aperture violation (gpurun_out/ab0.log: conv3x3_s3x_kernel, grid 256 workgroups x 768
+    threads = the persistent full-chip launch, which the small parity shapes never reach): 512-wide
+    images, more tiles than workgroups (every workgroup walks several tiles and batch slices, ragged last rows: H = 200 is not a
+    multiple of 16), forward and backward (input-gradient + weight-gradient).  Every plane the kernels read or write sits
+    between NaN guard bands inside one allocation: a load that strays returns NaN into the result, a store that strays breaks
+    a guard band.  Results are compared with the exact-fp32 mode of the same library (the oracle is too slow at this size;
+    the fp32 mode itself is pinned to the oracle by the small cases above)."""
+    from xmm_superres_denoise.engine import Engine
+    from xmm_superres_denoise.engine._lib import check
+    B, H, W = 5, 200, 512                      # 16 x 13 x 5 = 1040 tiles of 16 x 32 (2080 of 8 x 32) over 256 workgroups
+    gen = torch.Generator(device="cuda").manual_seed(1234 + n_in)
+    xs = [torch.randn((B, H, W, 32), device="cuda", generator=gen) for _ in range(n_in)]
+    gq = torch.randn((B, H, W, 32), device="cuda", generator=gen)
+    wd = torch.randn((32, 32 * n_in, 3, 3), device="cuda", generator=gen) / float(np.sqrt(288 * n_in))
+    bd = torch.randn((32,), device="cuda", generator=gen)
+
+    def run(e):
+        xin, chk_in = _guarded_planes(n_in, B, H, W, xs)
+        (gp,), chk_g = _guarded_planes(1, B, H, W, [gq])
+        outs, chk_out = _guarded_planes(1, B, H, W, None)
+        dxs, chk_dx = _guarded_planes(n_in, B, H, W, None)
+        dw, db = torch.full_like(wd, float("nan")), torch.full((32,), float("nan"), device="cuda")
+        check(e.L.xsd_test_conv3x3(e.h, ptr_array(xin), n_in, wd.data_ptr(), bd.data_ptr(), ptr_array(outs), 1, 0.2, B, H, W, None))
+        check(e.L.xsd_test_conv3x3_bwd(e.h, ptr_array(xin), n_in, wd.data_ptr(), gp.data_ptr(), ptr_array(dxs), dw.data_ptr(), db.data_ptr(), B, H, W, None))
+        torch.cuda.synchronize()
+        for c in (chk_in, chk_g, chk_out, chk_dx):
+            c()
+        for i in range(n_in):
+            assert torch.equal(xin[i], xs[i])          # inputs untouched
+        assert torch.equal(gp, gq)
+        res = [outs[0].clone()] + [d.clone() for d in dxs] + [dw, db]
+        assert all(bool(torch.isfinite(r).all()) for r in res)
+        return res
+
+    got = run(eng)
+    ref_eng = Engine("dn", 1, 1, 32, 1)
+    ref_eng.set_math("fp32")
+    ref = run(ref_eng)
+    for a, r in zip(got, ref):
+        assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-30

@@ -15,6 +15,9 @@ pytestmark = pytest.mark.gpu
 
 CASES = [("dn_nf32_b4_32x32", "dn"), ("dn_nf32_b4_24x40", "dn"), ("sr_nf32_b4_24x40", "sr"),
          ("sr_nf32_b4_17x45", "sr"), ("dn_nf32_b1_64x64", "dn")]
+# the reference's goldens at another width (8 filters: reduced model of SURVEY 7.1; full gradient tensors stored): the
+# generic-width path of the library (csrc/generic_net.hip, exact fp32, every math mode setting)
+NF8_CASES = [("dn_nf8_b1", "dn"), ("sr_nf8_b1", "sr"), ("sr_nf8_b1_up2", "sr")]
 
 
 def _relmax(a, b):
@@ -36,11 +39,10 @@ def _report_flips(tag, before):
                                                    f"{r['unexplained']} unexplained (max {r['max_rel_err']:.1e})" for r in recs))
 
 
-@pytest.mark.parametrize("math", MATHS)
-@pytest.mark.parametrize("name,kind", CASES)
+@pytest.mark.parametrize("name,kind,math", [(n, k, m) for n, k in CASES for m in MATHS] + [(n, k, "fp32") for n, k in NF8_CASES])
 def test_golden_forward_backward(name, kind, math):
     z, nf, blocks, nup, state, x, t = load_case(name, kind)
-    m = build_module(kind, blocks, nup, state).set_math(math)
+    m = build_module(kind, blocks, nup, state, nf=nf).set_math(math)
     xd = torch.from_numpy(x).cuda().requires_grad_(True)
     y = m(xd)
     assert np.abs(y.detach().cpu().numpy() - z["y"]).max() < 1e-4
@@ -367,3 +369,51 @@ def test_backward_rejects_mismatched_dy_and_stale_generation():
     eng.forward(x, save_for_backward=False)
     with pytest.raises(XsdError, match="preceding forward"):
         eng.backward(torch.zeros_like(y), grads)
+
+
+@pytest.mark.parametrize("kind,nf,in_ch,out_ch,blocks,nup,shape", [
+    ("dn", 64, 1, 1, 1, 1, (2, 20, 24)),     # the dense block's own default width (rrdb_blocks.py:23)
+    ("sr", 16, 3, 2, 2, 1, (2, 19, 21)),     # RGB in, two channels out, ragged against the 16 x 16 tile
+    ("dn", 12, 2, 2, 1, 1, (1, 33, 17)),     # width that is no multiple of 8
+    ("dn", 8, 1, 3, 1, 1, (2, 16, 16)),      # `out + x` with x broadcast over the output channels (generator_rrdb.py:134)
+    ("sr", 8, 1, 1, 1, 2, (1, 9, 11)),       # two pixel-shuffle stages
+])
+def test_generic_widths_vs_float64_restatement(kind, nf, in_ch, out_ch, blocks, nup, shape):
+    """Widths other than the shipped 32 / 1 / 1 (reference constructors take any: generator_rrdb.py:10-54) run on the
+    exact-fp32 direct-convolution kernels (csrc/generic_net.hip).  Forward, dL/dx and every parameter gradient against a
+    float64 evaluation of the reference graph (oracle.torch_forward; the C oracle handles one image channel only), through
+    the nn.Module API, L1 loss."""
+    from collections import OrderedDict
+    rng = np.random.default_rng(4242 + nf + in_ch)
+    shapes = gc.rrdb_param_shapes(kind, nf, blocks, in_ch=in_ch, out_ch=out_ch, num_upsample=nup)
+    state, fan = OrderedDict(), 1
+    for n, shp in shapes.items():
+        if n.endswith(".weight"):
+            fan = shp[1] * 9
+        state[n] = rng.uniform(-1, 1, size=shp).astype(np.float32) / np.sqrt(fan)
+    if kind == "sr":
+        state["conv_last.bias"][:] = 0.4
+    B, H, W = shape
+    s = 2 ** nup if kind == "sr" else 1
+    x = gc.make_input((B, in_ch, H, W), 11)
+    t = gc.make_input((B, out_ch, H * s, W * s), 12)
+    st64 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in state.items()}
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    y64 = oracle.torch_forward(kind, nf, blocks, st64, x64, num_upsample=nup)
+    l64 = torch.nn.functional.l1_loss(y64, torch.from_numpy(t).double())
+    l64.backward()
+    m = build_module(kind, blocks, nup, state, nf=nf, in_ch=in_ch, out_ch=out_ch)
+    xd = torch.from_numpy(x).cuda().requires_grad_(True)
+    y = m(xd)
+    assert y.shape == tuple(y64.shape)
+    assert np.abs(y.detach().cpu().numpy() - y64.detach().numpy()).max() < 2e-5
+    loss = torch.nn.functional.l1_loss(y, torch.from_numpy(t).cuda())
+    assert abs(loss.item() - l64.item()) < 1e-5
+    loss.backward()
+    cand_tol = dict(tight=2e-4, loose=5e-2, max_flip_frac=0.3)
+    assert_grad_close(xd.grad.cpu().numpy().reshape(-1, W), x64.grad.numpy().reshape(-1, W), "dx", **cand_tol)
+    for n, p in m.named_parameters():
+        assert_grad_close(p.grad.cpu().numpy(), st64[n].grad.numpy(), n, **cand_tol)
+    # and without autograd (no activations kept: two slabs ping-pong) the same output, bit for bit
+    with torch.no_grad():
+        assert torch.equal(m(xd.detach()), y.detach())

@@ -22,9 +22,9 @@ def load_case(name, kind):
     return z, nf, blocks, nup, state, x, t
 
 
-def build_module(kind, blocks, nup, state, device="cuda"):
+def build_module(kind, blocks, nup, state, device="cuda", nf=32, in_ch=1, out_ch=1):
     from xmm_superres_denoise.models import GeneratorRRDB_DN, GeneratorRRDB_SR
-    m = GeneratorRRDB_DN(1, 1, 32, blocks) if kind == "dn" else GeneratorRRDB_SR(1, 1, 32, blocks, num_upsample=nup)
+    m = GeneratorRRDB_DN(in_ch, out_ch, nf, blocks) if kind == "dn" else GeneratorRRDB_SR(in_ch, out_ch, nf, blocks, num_upsample=nup)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
     return m.to(device)
 

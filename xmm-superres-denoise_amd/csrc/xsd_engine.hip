@@ -24,6 +24,7 @@
 
 #include "../../include/xsd.h"
 #include "xsd_aux.h"
+#include "generic_net.h"
 #include "xsd_loss.h"
 
 static constexpr int EDGE_WGRAD_BLOCKS = 2048; // 8 workgroups of 256 threads per CU
@@ -68,6 +69,7 @@ struct ProfRec { hipEvent_t a, b; double flop, bytes; int klass; };
 
 struct xsd_engine {
     xsd_config cfg;
+    GenericNet* generic = nullptr;   // widths other than 32 filters / 1 image channel: exact-fp32 direct-conv kernels (generic_net.hip)
     long long nparams = 0;
     // flat-param offsets
     long long first_w = 0, first_b = 0, last_w = 0, last_b = 0;
@@ -638,14 +640,26 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
 {
     if (!cfg || !out) return fail(XSD_ERR_ARG, "null argument");
     if (cfg->kind != XSD_KIND_DN && cfg->kind != XSD_KIND_SR) return fail(XSD_ERR_ARG, "kind must be 0 (DN) or 1 (SR)");
-    if (cfg->in_channels != 1 || cfg->out_channels != 1) return fail(XSD_ERR_ARG, "engine supports in_channels = out_channels = 1 (got %d,%d)", cfg->in_channels, cfg->out_channels);
-    if (cfg->num_filters != 32) return fail(XSD_ERR_ARG, "engine is specialised for num_filters = 32 (got %d)", cfg->num_filters);
+    if (cfg->in_channels < 1 || cfg->out_channels < 1 || cfg->num_filters < 1 || cfg->in_channels > 1024 || cfg->out_channels > 1024 || cfg->num_filters > 1024)
+        return fail(XSD_ERR_ARG, "in_channels, out_channels and num_filters must be in [1,1024] (got %d,%d,%d)", cfg->in_channels, cfg->out_channels, cfg->num_filters);
+    // GeneratorRRDB_DN adds its input to the conv_last output (generator_rrdb.py:134): the shapes must broadcast
+    if (cfg->kind == XSD_KIND_DN && cfg->in_channels != cfg->out_channels && cfg->in_channels != 1)
+        return fail(XSD_ERR_ARG, "DN: `out + x` needs in_channels == out_channels or in_channels == 1 (got %d,%d)", cfg->in_channels, cfg->out_channels);
     if (cfg->num_res_blocks < 1 || cfg->num_res_blocks > 64) return fail(XSD_ERR_ARG, "num_res_blocks must be in [1,64]");
     if (cfg->kind == XSD_KIND_SR && (cfg->num_upsample < 1 || cfg->num_upsample > 2)) return fail(XSD_ERR_ARG, "num_upsample must be 1 or 2");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(XSD_ERR_HIP, "no HIP device available");
     xsd_engine* e = new xsd_engine();
     e->cfg = *cfg;
+    if (cfg->num_filters != 32 || cfg->in_channels != 1 || cfg->out_channels != 1) {
+        // not the shipped configuration (res/configs/models.toml: 32 filters, one image channel): the generic-width path
+        e->generic = GenericNet::create(*cfg);
+        if (!e->generic) { delete e; return fail(XSD_ERR_NOMEM, "generic-width engine: device allocation failed"); }
+        e->nparams = e->generic->nparams;
+        if (hipMalloc((void**)&e->loss_partial, sizeof(double) * 1024) != hipSuccess) { xsd_destroy(e); return fail(XSD_ERR_NOMEM, "device allocation failed"); }
+        *out = e;
+        return XSD_OK;
+    }
 #ifdef XSD_DIAG   // the diagnostic library variant (make diag, selected with XSD_LIB) is the only build that reads these
     if (const char* m = getenv("XSD_ABLATE")) e->ablate = atoi(m);
     if (const char* m = getenv("XSD_CHUNK")) e->chunk = atoi(m);
@@ -717,6 +731,7 @@ void xsd_destroy(xsd_engine* e)
 {
     if (!e) return;
     hipDeviceSynchronize();
+    delete e->generic;
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     hipFree(e->pk_fwd); hipFree(e->pk_bwd); hipFree(e->pk_fwd_s); hipFree(e->pk_bwd_s); hipFree(e->zero_page); hipFree(e->amax); hipFree(e->pk_edge); hipFree(e->pk_sbias); hipFree(e->descs_dev);
     hipFree(e->wg_partial); hipFree(e->wg_bias_partial); hipFree(e->edge_partial); hipFree(e->loss_partial);
@@ -729,6 +744,7 @@ int64_t xsd_param_count(const xsd_engine* e) { return e ? e->nparams : 0; }
 int xsd_set_math(xsd_engine* e, int mode)
 {
     if (!e || (mode != 0 && mode != 3 && mode != 4)) return fail(XSD_ERR_ARG, "math mode must be 0 (fp32, exact), 3 (bf16x6) or 4 (f16x3); modes 1 and 2 (16-bit significands) were removed in round 3");
+    if (e->generic) { e->math = mode; return XSD_OK; }   // the generic-width kernels are exact fp32 whatever the mode says
     if (mode != e->math) { e->math = mode; e->packed = false; e->pB = 0; e->ptrain = -1; e->fwd_saved = false; }
     return XSD_OK;
 }
@@ -739,6 +755,7 @@ int xsd_pack_weights(xsd_engine* e, const float* dev_params, void* stream)
     if (!e || !dev_params) return fail(XSD_ERR_ARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
     e->params = dev_params;
+    if (e->generic) { HIPCHK(e->generic->pack(dev_params, s)); e->packed = true; return XSD_OK; }
     if (e->math == 4) {
         // fp32 fragment-order panels into the (otherwise unused) mode-0 buffers, max |w| of the forward and of the
         // input-gradient panels (one power-of-two scale each), then the two-term fp16 images the conv kernel copies to LDS
@@ -766,6 +783,14 @@ int xsd_forward(xsd_engine* e, const float* dev_x, float* dev_y, int B, int H, i
     if (B < 1 || H < 1 || W < 1) return fail(XSD_ERR_ARG, "bad shape %dx%dx%d", B, H, W);
     if (!e->packed) return fail(XSD_ERR_STATE, "xsd_pack_weights must be called before xsd_forward");
     const int lo = e->cfg.kind == XSD_KIND_SR ? e->cfg.num_upsample : 0;
+    if (e->generic) {
+        const long long big = (long long)B * (H << lo) * (W << lo) * std::max(5 * e->cfg.num_filters, 4 * e->cfg.num_filters);
+        if (big >= (1ll << 40)) return fail(XSD_ERR_ARG, "batch x image too large");
+        hipError_t err = e->generic->forward(dev_x, dev_y, B, H, W, save_for_backward != 0, (hipStream_t)stream);
+        if (err != hipSuccess) return fail(err == hipErrorOutOfMemory ? XSD_ERR_NOMEM : XSD_ERR_HIP, "generic-width forward: %s", hipGetErrorString(err));
+        e->fwd_saved = save_for_backward != 0;
+        return XSD_OK;
+    }
     if ((long long)(H << lo) * (W << lo) * 32 >= (1ll << 31)) return fail(XSD_ERR_ARG, "image too large for 32-bit in-image offsets");
     // the split-mode kernels address a plane's batch slice with 32-bit BYTE offsets (buffer loads / stores): 128 B per pixel
     if (e->math >= 3 && (long long)(H << lo) * (W << lo) * 128 >= (1ll << 31))
@@ -787,6 +812,12 @@ int xsd_backward_stage(xsd_engine* e, int stage, const float* dev_dy, float* dev
 {
     if (!e || !dev_dy || !dev_grads) return fail(XSD_ERR_ARG, "null argument");
     if (!e->fwd_saved) return fail(XSD_ERR_STATE, "xsd_backward needs a preceding xsd_forward(save_for_backward=1)");
+    if (e->generic) {
+        if (stage < 0 || stage >= e->generic->num_stages()) return fail(XSD_ERR_ARG, "stage %d out of range", stage);
+        hipError_t err = e->generic->backward_stage(stage, dev_dy, dev_dx_or_null, dev_grads, (hipStream_t)stream);
+        if (err != hipSuccess) return fail(XSD_ERR_HIP, "generic-width backward stage %d: %s", stage, hipGetErrorString(err));
+        return XSD_OK;
+    }
     if (stage < 0 || stage >= (int)e->bwd_stages.size()) return fail(XSD_ERR_ARG, "stage %d out of range", stage);
     hipStream_t s = (hipStream_t)stream;
     e->b_dy = dev_dy; e->b_dx = dev_dx_or_null; e->b_grads = dev_grads;
@@ -810,6 +841,12 @@ int xsd_grad_range(const xsd_engine* e, int stage, int range_idx, int64_t* offse
     const int blocks = e->cfg.num_res_blocks;
     if (range_idx != 0 || stage < 0 || stage > blocks + 1) return 1;
     long long a, b;
+    if (e->generic) {
+        e->generic->grad_range(stage, &a, &b);
+        if (offset) *offset = a;
+        if (count) *count = b;
+        return 1;
+    }
     if (stage == 0) { a = e->rrdb_begin[blocks]; b = e->nparams; }
     else if (stage <= blocks) { const int i = blocks - stage; a = e->rrdb_begin[i]; b = e->rrdb_begin[i + 1]; }
     else { a = 0; b = e->rrdb_begin[0]; }
@@ -1023,6 +1060,7 @@ int xsd_test_conv3x3(xsd_engine* e, const float* const* in_planes, int n_in, con
                      float* const* out_planes, int n_out, float slope, int B, int H, int W, void* stream)
 {
     if (!e || n_in < 1 || n_in > 5 || n_out < 1 || n_out > 5 || (n_in > 1 && n_out > 1)) return fail(XSD_ERR_ARG, "bad n_in/n_out");
+    if (e->generic) return fail(XSD_ERR_ARG, "single-layer test hooks exist for the 32-filter MFMA path only");
     hipStream_t s = (hipStream_t)stream;
     float *fwd = nullptr, *bwd = nullptr;
     int rc = pack_single(dev_w_oihw, 32 * n_out, 32 * n_in, &fwd, &bwd, e->math, s, e->amax + xsd_engine::AMAX_CAP - 4);
@@ -1044,6 +1082,7 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
                          float* const* dx_planes, float* dev_dw_oihw, float* dev_db, int B, int H, int W, void* stream)
 {
     if (!e || n_in < 1 || n_in > 5) return fail(XSD_ERR_ARG, "bad n_in");
+    if (e->generic) return fail(XSD_ERR_ARG, "single-layer test hooks exist for the 32-filter MFMA path only");
     hipStream_t s = (hipStream_t)stream;
     float *fwd = nullptr, *bwd = nullptr;
     int rc = pack_single(dev_w_oihw, 32, 32 * n_in, &fwd, &bwd, e->math, s, e->amax + xsd_engine::AMAX_CAP - 4);

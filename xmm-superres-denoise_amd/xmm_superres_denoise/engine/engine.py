@@ -37,6 +37,7 @@ class Engine:
         check(self.L.xsd_create(ctypes.byref(cfg), ctypes.byref(h)))
         self.h = h
         self.kind = kind
+        self.in_channels, self.out_channels = int(in_channels), int(out_channels)
         self.scale = 2 ** num_upsample if kind == "sr" else 1
         self.nparams = int(self.L.xsd_param_count(self.h))
         self.num_stages = int(self.L.xsd_backward_num_stages(self.h))
@@ -80,10 +81,10 @@ class Engine:
     # ---- forward / backward
     def forward(self, x: torch.Tensor, save_for_backward: bool = False) -> torch.Tensor:
         _require_cuda_f32(x, "x")
-        if x.dim() != 4 or x.shape[1] != 1:
-            raise XsdError(f"x must be [B,1,H,W] (got {tuple(x.shape)})")
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise XsdError(f"x must be [B,{self.in_channels},H,W] (got {tuple(x.shape)})")
         B, _, H, W = x.shape
-        y = torch.empty((B, 1, H * self.scale, W * self.scale), device=x.device, dtype=torch.float32)
+        y = torch.empty((B, self.out_channels, H * self.scale, W * self.scale), device=x.device, dtype=torch.float32)
         check(self.L.xsd_forward(self.h, x.data_ptr(), y.data_ptr(), B, H, W, int(save_for_backward), _stream_ptr(x.device)))
         # any forward rebuilds / reuses the workspace, so previously saved activations are gone either way
         self._x_ref = x if save_for_backward else None  # conv_first's weight gradient re-reads x

@@ -87,7 +87,7 @@ class _EngineFn(torch.autograd.Function):
         eng = m._engine
         grads = torch.empty_like(m._flat)
         (x,) = ctx.saved_tensors
-        if tuple(dy.shape) != (x.shape[0], 1, x.shape[2] * eng.scale, x.shape[3] * eng.scale):
+        if tuple(dy.shape) != (x.shape[0], eng.out_channels, x.shape[2] * eng.scale, x.shape[3] * eng.scale):
             raise XsdError(f"dy has shape {tuple(dy.shape)} for an input of shape {tuple(x.shape)}")
         stale = not ctx.recompute and not eng.has_saved(ctx.generation)
         if (ctx.recompute or stale) and m._flat._version != ctx.flat_version:
@@ -119,11 +119,15 @@ class _GeneratorRRDB(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, num_filters: int, num_res_blocks: int,
                  memory_efficient: bool = False):
         super().__init__()
-        # The reference accepts any widths (generator_rrdb.py:10-54); this engine's kernels are specialised for the shipped
-        # configuration (res/configs/models.toml: 32 filters, one image channel).  Say so HERE, not at the first forward.
-        if in_channels != 1 or out_channels != 1 or num_filters != 32:
-            raise ValueError(f"the MI355X engine supports in_channels = out_channels = 1 and num_filters = 32 "
-                             f"(got {in_channels}, {out_channels}, {num_filters})")
+        # Any widths, like the reference (generator_rrdb.py:10-54).  The shipped configuration (res/configs/models.toml: 32
+        # filters, one image channel) runs on the MFMA kernels; every other one on the exact-fp32 direct-convolution kernels
+        # (csrc/generic_net.hip).  What cannot work is said HERE, not at the first forward.
+        for name, v in (("in_channels", in_channels), ("out_channels", out_channels), ("num_filters", num_filters)):
+            if not 1 <= int(v) <= 1024:
+                raise ValueError(f"{name} must be in [1, 1024] (got {v})")
+        if self._kind == "dn" and in_channels != out_channels and in_channels != 1:
+            raise ValueError(f"GeneratorRRDB_DN adds its input to the output (generator_rrdb.py:134): in_channels must equal "
+                             f"out_channels or be 1 (got {in_channels}, {out_channels})")
         if not 1 <= int(num_res_blocks) <= 64:
             raise ValueError(f"num_res_blocks must be in [1, 64] (got {num_res_blocks})")
         self.in_channels = in_channels
