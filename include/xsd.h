@@ -12,7 +12,7 @@
  *   conv_first.{weight,bias}, rrdb.{i}.RDB{r}.conv{c}.{weight,bias} (i<blocks, r=1..3, c=1..5), trunk_conv.*,
  *   conv_last.*, and for SR: upsampling.{3u}.* (u<num_upsample), HRconv.*
  *   (xmm_superres_denoise/models/modules/generator_rrdb.py:10-64,73-101; rrdb_blocks.py:23-32,60-64).
- * Images are NCHW with C = 1, i.e. plain [B][H][W] fp32.
+ * Images are NCHW fp32: x [B][in_channels][H][W], y [B][out_channels][sH][sW] (the shipped models have one channel: plain [B][H][W]).
  */
 #ifndef XSD_H
 #define XSD_H
@@ -39,9 +39,10 @@ enum xsd_kind { XSD_KIND_DN = 0, XSD_KIND_SR = 1 };
  * (generator_rrdb.py:114-121 / :73-81) as mapped from RrdbCfg by Model.configure_model (models/model.py:157-186). */
 typedef struct xsd_config {
     int32_t kind;          /* xsd_kind */
-    int32_t in_channels;   /* must be 1 */
-    int32_t out_channels;  /* must be 1 */
-    int32_t num_filters;   /* must be 32 (models.toml: filters = 32) */
+    int32_t in_channels;   /* 1..1024 (models.toml: 1).  DN: must equal out_channels or be 1 (`out + x`, generator_rrdb.py:134) */
+    int32_t out_channels;  /* 1..1024 (models.toml: 1) */
+    int32_t num_filters;   /* 1..1024 (models.toml: filters = 32).  32 filters with one image channel in and out run on the MFMA
+                              kernels; any other widths on the exact-fp32 direct-convolution kernels (csrc/generic_net.hip) */
     int32_t num_res_blocks;/* >= 1 (models.toml: residual_blocks = 4) */
     int32_t num_upsample;  /* SR only: (hr_res/lr_res)/2, 1 or 2 */
     int32_t memory_efficient; /* rrdb_blocks.py:39-47 recompute policy; numerics identical. Enforced by the host (chunked recompute), not here */
@@ -84,7 +85,7 @@ int xsd_get_math(const xsd_engine* e);
 int xsd_pack_weights(xsd_engine* e, const float* dev_params, void* stream);
 
 /* replaces Model.forward = clamp(GeneratorRRDB_*.forward(x), 0, 1) (models/model.py:48-49;
- * generator_rrdb.py:66-69,103-110,130-137).  x: [B][H][W]; y: [B][sH][sW], s = 2^num_upsample (SR) or 1 (DN).
+ * generator_rrdb.py:66-69,103-110,130-137).  x: [B][in_channels][H][W]; y: [B][out_channels][sH][sW], s = 2^num_upsample (SR) or 1 (DN).
  * save_for_backward != 0 keeps every activation needed by xsd_backward (about 7.7 KB per LR pixel). */
 int xsd_forward(xsd_engine* e, const float* dev_x, float* dev_y, int B, int H, int W, int save_for_backward, void* stream);
 

@@ -112,7 +112,7 @@ def test_train_driver_two_ranks(tmp_path):
         env["XSD_DIST_BACKEND"] = "gloo"
     ck = os.path.join(tmp_path, "dp.ckpt")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), "-m", "xmm_superres_denoise.train", "fit", "--lr-res", "256", "--batch-size", "4",
+           "--master-port", str(_free_port()), "-m", "xmm_superres_denoise.train", "fit", "--lr-res", "320", "--batch-size", "4",
            "--steps", "3", "--val-batches", "1", "--checkpoint", ck]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
     out = p.stdout.decode(errors="replace")

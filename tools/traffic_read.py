@@ -1,8 +1,9 @@
-"""Summarise the FETCH_SIZE / WRITE_SIZE passes of tools/traffic.sh into profiles/r02_traffic_<math>.json.
+"""Summarise the FETCH_SIZE / WRITE_SIZE passes of tools/traffic.sh into gpurun_out/<tag>_traffic_<math>.json (tag = argv[3], default r03).
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream,
 so read bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact for 16-B-per-lane stores.  Both counters are in KiB."""
 import collections, csv, glob, json, os, sys
 math, B = sys.argv[1], int(sys.argv[2])
+TAG = sys.argv[3] if len(sys.argv) > 3 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(int)
@@ -24,5 +25,5 @@ for name in agg:
     wr = agg[name]["WRITE_SIZE"] * 1024 / n
     out[name] = {"launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "traffic_bytes_per_launch": rd + wr}
 os.makedirs(f"{ROOT}/gpurun_out", exist_ok=True)
-json.dump(out, open(f"{ROOT}/gpurun_out/r02_traffic_{math}.json", "w"), indent=1)
+json.dump(out, open(f"{ROOT}/gpurun_out/{TAG}_traffic_{math}.json", "w"), indent=1)
 print(json.dumps(out))

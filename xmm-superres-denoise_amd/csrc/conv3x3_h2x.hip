@@ -395,14 +395,13 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
         // Three slots each: an input fragment lives 3 steps; a weight fragment (dy, dx), numbered n = 3 dx + dy in the order
         // of first use, is requested two steps before its step 4 dx + dy and used there (row 0) and in the next step
         // (row 1) -- any four consecutive n straddle a column change, i.e. an extra step, so n % 3 never collides.
+        // (Round 3 A/B, one device: the reads of step s+2 interleaved one behind each MFMA of step s by sched_group_barrier
+        // instead of issued as a block: conv -0.5 % forward / -0.9 % in the train step, inside the run-to-run spread of 0.8 %;
+        // the four reads step 0 needs forced in front of the other four: no change.  Not adopted.)
         load_x(0, 0, xf[0]);
         load_w(0, wf[0]);
-#ifdef X3_HEAD
-        __builtin_amdgcn_sched_barrier(0);   // experiment: the four reads step 0 needs go first (hipcc orders the eight as it likes otherwise)
-#endif
         load_x(1, 0, xf[1]);
         load_w(1 * 3 + 0, wf[1]);
-#ifndef X3_IL
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
             const int dx = s >> 2, ir = s & 3;
@@ -417,38 +416,6 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
             if (drip && s >= 1 && s <= 8) store_pending(s - 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-#else
-        // experiment X3_IL: the reads of step s+2 are INTERLEAVED with the MFMAs of step s (one ds_read_b128 behind each MFMA)
-        // instead of issued as a block in front of them: an in-order wave's non-MFMA instructions hide in the shadow of the
-        // MFMA they follow (8 issue cycles of its 32) only when at most a few sit between two MFMAs
-        auto step = [&](auto SC) {
-            constexpr int s = decltype(SC)::value;
-            constexpr int dx = s >> 2, ir = s & 3;
-            constexpr int nm = (ir >= 1 ? 3 : 0) + (ir <= 2 ? 3 : 0);
-            constexpr int nr = (s + 2 < 12) ? (2 + ((((s + 2) & 3) <= 2) ? 2 : 0)) : 0;
-            if constexpr (s + 2 < 12) {
-                constexpr int dx2 = (s + 2) >> 2, ir2 = (s + 2) & 3;
-                load_x(ir2, dx2, xf[(s + 2) % 3]);
-                if constexpr (ir2 <= 2) load_w(ir2 * 3 + dx2, wf[(3 * dx2 + ir2) % 3]);
-            }
-            if constexpr (ir >= 1) mac(1, wf[(3 * dx + ir - 1) % 3], xf[s % 3]);
-            if constexpr (ir <= 2) mac(0, wf[(3 * dx + ir) % 3], xf[s % 3]);
-            // pipeline of this region: MFMA, read, MFMA, read, ... then the remaining MFMAs
-            if constexpr (nm > 0) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); if constexpr (nr > 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-            if constexpr (nm > 1) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); if constexpr (nr > 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-            if constexpr (nm > 2) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); if constexpr (nr > 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-            if constexpr (nm > 3) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); if constexpr (nr > 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-            if constexpr (nm > 4) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if constexpr (nm > 5) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if constexpr (s >= 1 && s <= 8) { if (drip) store_pending(s - 1); }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        __builtin_amdgcn_sched_barrier(0);
-        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
-        step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
-        step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
-        step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
-#endif
     };
 
     // Epilogue over fp32 planes (straight-line operand variants; lanes outside the image read the zero page and write a
