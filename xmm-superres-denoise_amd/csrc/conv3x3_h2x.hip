@@ -397,7 +397,9 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
         // (row 1) -- any four consecutive n straddle a column change, i.e. an extra step, so n % 3 never collides.
         // (Round 3 A/B, one device: the reads of step s+2 interleaved one behind each MFMA of step s by sched_group_barrier
         // instead of issued as a block: conv -0.5 % forward / -0.9 % in the train step, inside the run-to-run spread of 0.8 %;
-        // the four reads step 0 needs forced in front of the other four: no change.  Not adopted.)
+        // the four reads step 0 needs forced in front of the other four: no change.  Two half workgroups per CU (2 staging + 4
+        // MFMA waves, 8 x 32 tiles, 81 KB of LDS each: independent barrier domains; with and without a start stagger): conv
+        // +15 % time (1.394 -> 1.603 ms per launch), the weight gradient beside it -7 % (power).  None adopted.)
         load_x(0, 0, xf[0]);
         load_w(0, wf[0]);
         load_x(1, 0, xf[1]);
