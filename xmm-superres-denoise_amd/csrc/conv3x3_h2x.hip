@@ -399,7 +399,10 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
         // instead of issued as a block: conv -0.5 % forward / -0.9 % in the train step, inside the run-to-run spread of 0.8 %;
         // the four reads step 0 needs forced in front of the other four: no change.  Two half workgroups per CU (2 staging + 4
         // MFMA waves, 8 x 32 tiles, 81 KB of LDS each: independent barrier domains; with and without a start stagger): conv
-        // +15 % time (1.394 -> 1.603 ms per launch), the weight gradient beside it -7 % (power).  None adopted.)
+        // +15 % time (1.394 -> 1.603 ms per launch), the weight gradient beside it -7 % (power).  ONE MFMA wave per SIMD with
+        // three tile rows (12 x 32 tile, 4 + 4 waves, 256 registers, no spills) and its reads interleaved one behind each MFMA --
+        // the configuration a flag-synchronised ring would need: +9 % time (1.415 -> 1.546 ms; round 2 measured +8.6 % for four
+        // rows without the interleave): a lone in-order wave reaches 48 cycles per MFMA here, not 32.  None adopted.)
         load_x(0, 0, xf[0]);
         load_w(0, wf[0]);
         load_x(1, 0, xf[1]);
