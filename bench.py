@@ -241,6 +241,14 @@ def main():
     from xmm_superres_denoise.models import GeneratorRRDB_DN, GeneratorRRDB_SR
     from xmm_superres_denoise.parallel import DataParallelTrainer
 
+    trace_on = bool(os.environ.get("XSD_BENCH_TRACE"))
+
+    def trace(msg):      # progress markers of every rank on stderr (diagnosing a multi-rank run that does not come back)
+        if trace_on:
+            print(f"[bench rank {rank}/{world} +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    t_start = time.perf_counter()
+    trace("process group up")
     kind, mode = args.workload.split("_")
     train = mode == "train"
     B = args.batch or (16 if args.workload == "sr_fwd" else 32)
@@ -263,6 +271,7 @@ def main():
         loss_fn = create_loss(*load_loss_config("linear"))
     trainer = DataParallelTrainer(model, lr=1e-4, betas=(0.9, 0.999), loss=loss_fn)
     eng = trainer.engine
+    trace("trainer built (parameters broadcast)")
 
     counts = mask = None
     if args.input_pipeline:
@@ -288,22 +297,25 @@ def main():
             return model(x)
 
     def timed(nwarm, nsteps, profile):
-        for _ in range(nwarm):
+        for i in range(nwarm):
             step()
+            trace(f"warm-up step {i} enqueued")
         if profile:
             eng.profile_enable(True)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        trace("timed region starts")
         t0 = time.perf_counter()
         for _ in range(nsteps):
             step()
         torch.cuda.synchronize()
+        trace("timed region done")
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         prof = None

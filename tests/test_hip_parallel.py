@@ -76,28 +76,31 @@ def test_two_ranks_on_hip_engine_match_single_process_full_batch(tmp_path, math,
     assert np.abs(res[0]["params"][-1] - res[0]["params"][0]).max() > 1e-4
 
 
-def test_bench_two_ranks_gloo_on_one_gpu():
-    """`python bench.py --gpus 2` as the driver launches it for N > 1 (self-launching here): two ranks, one process each, the
-    DP train step with the staged all-reduce; over RCCL when two GPUs are visible, else both ranks share cuda:0 over gloo.
-    The JSON line carries the whole-job value and the DDP invariant (bit-identical replicas after the timed steps)."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_n_ranks_gloo_on_one_gpu(world):
+    """`python bench.py --gpus N` as the driver launches it for N > 1 (self-launching here): N ranks, one process each, the
+    DP train step with the staged all-reduce; over RCCL when N GPUs are visible, else the ranks share cuda:0 over gloo.
+    The JSON line carries the whole-job value and the DDP invariant (bit-identical replicas after the timed steps).
+    (Four ranks: round 3 found gloo's own device all-reduce never returning with a power-of-two number of ranks on one GPU;
+    under gloo the gradient slices are reduced through a pinned host buffer since, parallel.py.)"""
     import json
     root = os.path.dirname(HERE)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    if torch.cuda.device_count() < 2:
+    if torch.cuda.device_count() < world:
         env["XSD_DIST_BACKEND"] = "gloo"
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
-                        "--no-extra", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--no-extra", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = p.stdout.decode(errors="replace")
     assert p.returncode == 0, out[-3000:]
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out[-3000:]          # rank 0 prints exactly one JSON line
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and d["steps"] == 2
-    assert d["config"]["per_gpu_batch"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["n_gpus"] == world and d["value"] > 0 and d["scaling"] == "weak" and d["steps"] == 2
+    assert d["config"]["per_gpu_batch"] == 2 and d["config"]["global_batch"] == 2 * world and d["config"]["parallelism"] == f"dp{world}"
     assert d["replicas_identical"] is True
-    assert abs(d["value"] - 4 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]      # value = all ranks' tiles / max-over-ranks time
+    assert abs(d["value"] - 2 * world * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]      # value = all ranks' tiles / max-over-ranks time
     assert d["roofline"]["launches"] > 0
 
 

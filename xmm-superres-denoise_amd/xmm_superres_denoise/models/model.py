@@ -23,6 +23,8 @@ def _mean_over_ranks(values: dict) -> dict:
     t = torch.stack([torch.as_tensor(values[k]).detach().double().reshape(()) for k in keys])
     if dist.get_backend() == "nccl":
         t = t.cuda()
+    else:
+        t = t.cpu()
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     t = (t / dist.get_world_size()).float()
     return {k: t[i] for i, k in enumerate(keys)}

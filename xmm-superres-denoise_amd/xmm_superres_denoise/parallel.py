@@ -16,6 +16,19 @@ import torch
 import torch.distributed as dist
 
 
+def all_reduce_any(t: torch.Tensor, op=None, group=None) -> torch.Tensor:
+    """dist.all_reduce in place, wherever `t` lives: device tensors go through the host under gloo (whose own CUDA algorithms hung
+    with four ranks sharing one MI355X: DataParallelTrainer), stay on the device under RCCL."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 class DataParallelTrainer:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, engine=None,
                  process_group=None, loss=None):
@@ -32,9 +45,20 @@ class DataParallelTrainer:
         self.step_count = 0
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # gloo (the rehearsal backend for boxes with fewer GPUs than ranks) reduces device tensors with its own CUDA algorithms; with
+        # four ranks sharing ONE MI355X its power-of-two algorithm never returned (three ranks, ring, did).  Under gloo the gradient
+        # slices therefore travel through a pinned host buffer and are reduced as CPU tensors; RCCL ("nccl") reduces in place on
+        # the device, asynchronously, as before.
+        self._host = None
         if self.world > 1:
             # replicas must start identical (DDP broadcasts rank 0's parameters at construction)
-            dist.broadcast(self.flat, src=0, group=process_group)
+            if dist.get_backend(process_group) == "gloo" and self.flat.is_cuda:
+                self._host = torch.empty(self.flat.numel(), dtype=torch.float32).pin_memory()
+                self._host.copy_(self.flat)
+                dist.broadcast(self._host, src=0, group=process_group)
+                self.flat.copy_(self._host)
+            else:
+                dist.broadcast(self.flat, src=0, group=process_group)
 
     def shard(self, global_batch: torch.Tensor) -> torch.Tensor:
         """This rank's contiguous slice of a global minibatch (DistributedSampler analogue, no shuffling)."""
@@ -60,7 +84,13 @@ class DataParallelTrainer:
         def reduce_stage(st):
             if self.world > 1:
                 off, cnt = eng.grad_range(st)
-                works.append(dist.all_reduce(self.grads[off:off + cnt], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                if self._host is None:
+                    works.append((dist.all_reduce(self.grads[off:off + cnt], op=dist.ReduceOp.SUM, group=self.pg, async_op=True), None))
+                else:       # gloo: device -> pinned host (after the stage's kernels), reduce on the host while later stages compute
+                    h = self._host[off:off + cnt]
+                    h.copy_(self.grads[off:off + cnt], non_blocking=True)
+                    torch.cuda.current_stream(self.grads.device).synchronize()
+                    works.append((dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), (off, cnt)))
 
         if recompute:
             backward_recompute(eng, x, dy, self.grads, False, me_chunk(), reduce_stage)
@@ -68,8 +98,11 @@ class DataParallelTrainer:
             for st in range(eng.num_stages):
                 eng.backward_stage(st, dy, self.grads)
                 reduce_stage(st)
-        for w in works:
+        for w, back in works:
             w.wait()
+            if back is not None:
+                off, cnt = back
+                self.grads[off:off + cnt].copy_(self._host[off:off + cnt], non_blocking=True)
         self.step_count += 1
         eng.adam_step(self.flat, self.grads, self.m, self.v, self.step_count, self.lr, self.betas, self.eps,
                       grad_scale=1.0 / self.world)
@@ -80,5 +113,5 @@ class DataParallelTrainer:
         if self.world == 1:
             return local_loss
         t = local_loss.detach().clone()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        all_reduce_any(t, dist.ReduceOp.SUM, self.pg)
         return t / self.world

@@ -95,9 +95,10 @@ class EpochState:
             a = torch.zeros(9, dtype=torch.float64, device=device)
         sums = a[[0, 1, 4, 5, 6, 7, 8]].contiguous()
         lo, hi = a[2:3].contiguous(), a[3:4].contiguous()
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        from xmm_superres_denoise.parallel import all_reduce_any
+        all_reduce_any(sums, dist.ReduceOp.SUM, group)
+        all_reduce_any(lo, dist.ReduceOp.MIN, group)
+        all_reduce_any(hi, dist.ReduceOp.MAX, group)
         if float(sums[1]) == 0.0:
             self.acc = None
             return
