@@ -377,6 +377,7 @@ def test_backward_rejects_mismatched_dy_and_stale_generation():
     ("dn", 12, 2, 2, 1, 1, (1, 33, 17)),     # width that is no multiple of 8
     ("dn", 8, 1, 3, 1, 1, (2, 16, 16)),      # `out + x` with x broadcast over the output channels (generator_rrdb.py:134)
     ("sr", 8, 1, 1, 1, 2, (1, 9, 11)),       # two pixel-shuffle stages
+    ("dn", 64, 3, 3, 2, 1, (2, 70, 133)),    # several 16 x 16 tiles per image, 320-channel dense convs, RGB with the skip
 ])
 def test_generic_widths_vs_float64_restatement(kind, nf, in_ch, out_ch, blocks, nup, shape):
     """Widths other than the shipped 32 / 1 / 1 (reference constructors take any: generator_rrdb.py:10-54) run on the
