@@ -23,7 +23,7 @@ for n,c in zip(names,v[:6]): print(f'  {n:24s} {c/max(v[6],1):10.0f} cycles/item
 if v[7]: print(f'  in-kernel clock (stamped cycles / s_memrealtime at 100 MHz): {tot/v[7]*0.1:.3f} GHz')
 if any(v[8:13]):
     print('  staging wave 0 (role-split kernel):')
-    for n,c in zip(['input rounds','weight rounds','wait barrier A','weight write','barrier B + bookkeeping'],v[8:13]): print(f'  {n:24s} {c/max(v[6],1):10.0f} cycles/item')
+    for n,c in zip(['input rounds (incl. data waits)','wait for DMA pieces','barrier','of the input rounds: counted data waits','descriptors + DMA issue'],v[8:13]): print(f'  {n:24s} {c/max(v[6],1):10.0f} cycles/item')
 if any(v[13:16]):
     print('  youngest MFMA wave (role-split kernel):')
     for n,c in zip(['MFMA loop','epilogue','wait+barrier1'],v[13:16]): print(f'  {n:24s} {c/max(v[6],1):10.0f} cycles/item')

@@ -289,7 +289,14 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
             // input of half-step it+1: registers -> the other buffer; then refill each register with half-step it+2
 #pragma unroll
             for (int r = 0; r < X3_XR; r += 2) {     // two rounds at a time: four independent split chains in flight
+#ifdef XSD_DIAG   // slot 11: cycles the staging wave spends in its counted waits, i.e. waiting for load data
+                unsigned long long w0_ = 0;
+                if (lstamp) w0_ = __builtin_readcyclecounter();
+#endif
                 if (!(abl & 4)) asm_wait13(pin[r], pin[r + 1]);
+#ifdef XSD_DIAG
+                if (lstamp) lst[3] += __builtin_readcyclecounter() - w0_;
+#endif
                 store_x_round(r, xn);
                 store_x_round(r + 1, xn);
                 if (!(abl & 4)) { load_x_round(r, xrs); load_x_round(r + 1, xrs); }
