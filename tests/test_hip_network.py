@@ -377,11 +377,13 @@ def test_backward_rejects_mismatched_dy_and_stale_generation():
     ("dn", 12, 2, 2, 1, 1, (1, 33, 17)),     # width that is no multiple of 8
     ("dn", 8, 1, 3, 1, 1, (2, 16, 16)),      # `out + x` with x broadcast over the output channels (generator_rrdb.py:134)
     ("sr", 8, 1, 1, 1, 2, (1, 9, 11)),       # two pixel-shuffle stages
-    ("dn", 64, 3, 3, 2, 1, (2, 70, 133)),    # several 16 x 16 tiles per image, 320-channel dense convs, RGB with the skip
+    ("dn", 64, 3, 3, 2, 1, (2, 70, 133)),    # several tiles per image, 320-channel dense convs, RGB with the skip
+    ("sr", 48, 1, 1, 1, 1, (1, 21, 45)),     # matrix-instruction path with partial 32-channel blocks (48 .. 240 inputs, 192-channel shuffle conv), ragged against its 8 x 32 tile
 ])
 def test_generic_widths_vs_float64_restatement(kind, nf, in_ch, out_ch, blocks, nup, shape):
     """Widths other than the shipped 32 / 1 / 1 (reference constructors take any: generator_rrdb.py:10-54) run on the
-    exact-fp32 direct-convolution kernels (csrc/generic_net.hip).  Forward, dL/dx and every parameter gradient against a
+    exact-fp32 kernels of csrc/generic_net.hip: convs with >= 16 channels on both sides on the fp32 matrix instruction (the
+    64-, 48- and 16-filter cases), narrower ones as direct convolutions.  Forward, dL/dx and every parameter gradient against a
     float64 evaluation of the reference graph (oracle.torch_forward; the C oracle handles one image channel only), through
     the nn.Module API, L1 loss."""
     from collections import OrderedDict

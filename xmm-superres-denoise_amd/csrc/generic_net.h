@@ -9,7 +9,11 @@
 
 namespace xsd {
 
-struct GConvW { long long w, b, t; int cout, cin; };   // flat-param offsets of weight / bias, offset of the transposed copy
+struct GConvW {              // flat-param offsets of weight / bias, offset of the transposed copy, offsets of the block-packed copies
+    long long w, b, t, pf, pt;
+    int cout, cin;
+    bool wide() const { return cout >= 16 && cin >= 16; }     // runs on the fp32 matrix instruction
+};
 
 struct GenericNet {
     static constexpr int MAX_PARTS = 64;
@@ -22,6 +26,8 @@ struct GenericNet {
     std::vector<long long> rrdb_begin;
     int ndesc = 0, max_w = 0;
     float* wt = nullptr;             // transposed + flipped weights (input-gradient convs), rebuilt by pack()
+    float* wblk = nullptr;           // [co block][ci block][tap][32][32] copies of the wide convs and their input-gradient convs
+    long long wblk_floats = 0;
     void* descs_dev = nullptr;
     const float* params = nullptr;   // borrowed
     bool packed = false, saved = false;

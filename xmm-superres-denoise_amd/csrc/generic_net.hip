@@ -2,9 +2,10 @@
 //
 // The reference's constructors accept any widths (generator_rrdb.py:10-54; config/config.py:164-203 PositiveInt; the dense
 // block's own default is nf = 64, rrdb_blocks.py:23); the MFMA path of this library is specialised for the shipped
-// configuration (32 filters, one image channel, res/configs/models.toml).  Every other configuration runs here: hand-written
-// HIP direct-convolution kernels in exact fp32 (fmaf chains on the vector ALUs, no matrix cores, no split arithmetic; the
-// math mode of xsd_set_math does not apply), NCHW tensors like the reference's.  Same C ABI, same flat parameter layout, same
+// configuration (32 filters, one image channel, res/configs/models.toml).  Every other configuration runs here, in exact fp32
+// (the math mode of xsd_set_math does not apply), on NCHW tensors like the reference's: convs with at least 16 channels on
+// both sides on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32, an fmaf chain: gconv_mfma_kernel, gwgrad_mfma_kernel),
+// narrower ones (the image-side convs; every conv of an 8-filter net) as direct convolutions on the vector ALUs.  Same C ABI, same flat parameter layout, same
 // backward stages as the MFMA path (xsd_engine.hip dispatches on the configuration).
 //
 // Layout.  torch.cat of the dense block (rrdb_blocks.py:49-52) is a channel PREFIX of one slab [B][5 nf][H][W] per dense
@@ -52,6 +53,25 @@ struct GConvP {
     int clamp01;
 };
 
+// one output element through the fused epilogue (shared by the direct and the MFMA kernel)
+__device__ __forceinline__ void gconv_store(const GConvP& P, int b, int co, int gy, int gx, float acc)
+{
+    const long long HW = (long long)P.H * P.W, pix = (long long)gy * P.W + gx;
+    float v = (acc + (P.bias ? P.bias[co] : 0.f)) * P.a1;
+    if (P.e1 && co < P.e1c) v += P.s1 * P.e1[(long long)b * P.e1bs + co * HW + pix];
+    v *= P.a2;
+    if (P.e2) v += P.s2 * P.e2[(long long)b * P.e2bs + co * HW + pix];
+    v = v > 0.f ? v : v * P.slope;
+    if (P.skip) v += P.skip[(long long)b * P.skipbs + (P.skipc == 1 ? 0 : co) * HW + pix];
+    long long o;
+    if (P.shuffle) o = (long long)b * P.ybs + (long long)(co >> 2) * 4 * HW + (long long)(2 * gy + ((co >> 1) & 1)) * (2 * P.W) + 2 * gx + (co & 1);
+    else o = (long long)b * P.ybs + co * HW + pix;
+    if (P.accumulate) v += P.y[o];
+    if (P.pre) P.pre[o] = v;
+    if (P.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+    P.y[o] = v;
+}
+
 constexpr int GT = 16;              // 16 x 16 pixel tile per workgroup
 constexpr int GCO = 8, GCI = 8;     // output channels per thread / input channels per LDS round
 
@@ -96,36 +116,229 @@ __global__ __launch_bounds__(256) void gconv3x3_kernel(const GConvP P)
     }
     const int gx = x0 + tx, gy = y0 + ty;
     if (gx >= P.W || gy >= P.H) return;
-    const long long pix = (long long)gy * P.W + gx;
 #pragma unroll
     for (int k = 0; k < GCO; ++k) {
-        const int co = co0 + k;
-        if (co >= P.cout) break;
-        float v = (acc[k] + (P.bias ? P.bias[co] : 0.f)) * P.a1;
-        if (P.e1 && co < P.e1c) v += P.s1 * P.e1[(long long)b * P.e1bs + co * HW + pix];
-        v *= P.a2;
-        if (P.e2) v += P.s2 * P.e2[(long long)b * P.e2bs + co * HW + pix];
-        v = v > 0.f ? v : v * P.slope;
-        if (P.skip) v += P.skip[(long long)b * P.skipbs + (P.skipc == 1 ? 0 : co) * HW + pix];
-        long long o;
-        if (P.shuffle) o = (long long)b * P.ybs + (long long)(co >> 2) * 4 * HW + (long long)(2 * gy + ((co >> 1) & 1)) * (2 * P.W) + 2 * gx + (co & 1);
-        else o = (long long)b * P.ybs + co * HW + pix;
-        if (P.accumulate) v += P.y[o];
-        if (P.pre) P.pre[o] = v;
-        if (P.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
-        P.y[o] = v;
+        if (co0 + k >= P.cout) break;
+        gconv_store(P, b, co0 + k, gy, gx, acc[k]);
     }
 }
 
-// weight gradient, stage 1: partial[part][co][ci][9] = sum over the part's pixels of g[b,co,p] * x[b,ci,p + tap];
-// bias_partial[part][co] = sum g (blocks with ci == 0).  grid (cin, cout, parts), 256 threads, fixed-order LDS tree.
+// The same convolution on the exact-fp32 matrix instruction, for convs with at least 16 channels on both sides:
+// D[co][px] = sum over (ci, tap) of W[co][ci][tap] X[ci][px + tap] as v_mfma_f32_32x32x2_f32 products with K = two input
+// channels per instruction: lane l supplies W[co = l % 32][ci = 2 c2 + l / 32][tap] and X[that ci][pixel l % 32 + tap shift].
+// A workgroup (4 waves) owns 32 output channels x an 8 x 32 pixel tile, wave w the rows 2w, 2w + 1 (two accumulators); per
+// block of 32 input channels the X halo tile ([32][10 x 34], channel stride 341 words) and the weight block ([9][32 ci][32 co],
+// pre-arranged and zero-padded by gpack_blocks_kernel: one contiguous 36,864-B copy) go through LDS: 80.5 KB, two workgroups
+// per CU.  Summation order: input channels ascending in pairs, taps inside; exact fp32 (the MFMA is an fmaf chain).
+typedef float gf32x16 __attribute__((ext_vector_type(16)));
+constexpr int GW_ROWS = 8, GW_COLS = 32;
+constexpr int GW_XCH = (GW_ROWS + 2) * (GW_COLS + 2) + 1;     // 341 words per X channel
+constexpr int GW_GCH = GW_ROWS * GW_COLS + 1;                 // 257 words per G channel (weight gradient)
+constexpr int GM_LDS_BYTES = (32 * GW_XCH + 9 * 1024) * 4;    // 80,512
+
+// Tile staging of the matrix-instruction kernels.  Loads are BUFFER loads against a descriptor of the (at most 32) channels
+// being staged: channels past the tensor fail the hardware range check and read as zero, pixels outside the image get an
+// offset that fails it too -- no select on the data, no access outside the tensor.  A thread requests GS_CHUNK elements
+// before it writes the first to LDS (memory-level parallelism; one element at a time is a round trip each; the weight
+// gradient with its 144 accumulator registers affords 4, the conv 11).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gchan_rsrc(const float* base, int nch, long long HW)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)((long long)(nch < 32 ? nch : 32) * HW * 4), 0x00020000);
+}
+// X halo tile [32][10 x 34] (channel stride GW_XCH) of the channels the descriptor covers
+template <int GS_CHUNK>
+__device__ __forceinline__ void gstage_x(float* xs, __amdgpu_buffer_rsrc_t rs, int y0, int x0, int H, int W, int HW, int tid)
+{
+    constexpr int PX = (GW_ROWS + 2) * (GW_COLS + 2), N = 32 * PX, K = (N + 255) / 256;
+#pragma unroll 1
+    for (int k0 = 0; k0 < K; k0 += GS_CHUNK) {
+        float v[GS_CHUNK];
+        int li[GS_CHUNK];
+#pragma unroll
+        for (int q = 0; q < GS_CHUNK; ++q) {
+            if (k0 + q >= K) continue;
+            const int i = tid + 256 * (k0 + q);
+            const int c = i / PX, r = i - c * PX, hy = r / (GW_COLS + 2), hx = r - hy * (GW_COLS + 2);
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            const bool ok = i < N && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (c * HW + gy * W + gx) * 4 : (int)0x80000000, 0, 0));
+            li[q] = i < N ? i + c : -1;                    // c * GW_XCH + r
+        }
+#pragma unroll
+        for (int q = 0; q < GS_CHUNK; ++q)
+            if (k0 + q < K && li[q] >= 0) xs[li[q]] = v[q];
+    }
+}
+// G tile [32][8 x 32] (channel stride GW_GCH)
+template <int GS_CHUNK>
+__device__ __forceinline__ void gstage_g(float* gs, int gch, __amdgpu_buffer_rsrc_t rs, int y0, int x0, int H, int W, int HW, int tid)
+{
+    constexpr int PX = GW_ROWS * GW_COLS, K = 32 * PX / 256;     // 32 elements per thread
+    static_assert(K % GS_CHUNK == 0, "chunk");
+#pragma unroll 1
+    for (int k0 = 0; k0 < K; k0 += GS_CHUNK) {
+        float v[GS_CHUNK];
+#pragma unroll
+        for (int q = 0; q < GS_CHUNK; ++q) {
+            const int i = tid + 256 * (k0 + q), c = i / PX, r = i & (PX - 1);
+            const int gy = y0 + (r >> 5), gx = x0 + (r & 31);
+            v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (gy < H && gx < W) ? (c * HW + gy * W + gx) * 4 : (int)0x80000000, 0, 0));
+        }
+#pragma unroll
+        for (int q = 0; q < GS_CHUNK; ++q) {
+            const int i = tid + 256 * (k0 + q), c = i / PX, r = i & (PX - 1);
+            gs[c * gch + r] = v[q];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const GConvP P)     // P.w: the conv's block-packed weights
+{
+    extern __shared__ __attribute__((aligned(16))) float gm_lds[];
+    float* xs = gm_lds;
+    float* wl = gm_lds + 32 * GW_XCH;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kk = lane >> 5;
+    const int tilesX = (P.W + GW_COLS - 1) / GW_COLS;
+    const int x0 = ((int)blockIdx.x % tilesX) * GW_COLS, y0 = ((int)blockIdx.x / tilesX) * GW_ROWS;
+    const int cob = blockIdx.y, b = blockIdx.z;
+    const int nci = (P.cin + 31) / 32;
+    const long long HW = (long long)P.H * P.W;
+    const float* xb = P.x + (long long)b * P.xbs;
+    gf32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
+    for (int cib = 0; cib < nci; ++cib) {
+        __syncthreads();
+        gstage_x<11>(xs, gchan_rsrc(xb + (long long)cib * 32 * HW, P.cin - cib * 32, HW), y0, x0, P.H, P.W, (int)HW, tid);
+        const float4* wsrc = reinterpret_cast<const float4*>(P.w + ((long long)cob * nci + cib) * (9 * 1024));
+        for (int i = tid; i < 9 * 256; i += 256) reinterpret_cast<float4*>(wl)[i] = wsrc[i];
+        __syncthreads();
+        const float* xl = xs + kk * GW_XCH + (2 * wave) * (GW_COLS + 2) + j;
+        const float* wp = wl + kk * 32 + j;
+#pragma unroll 2
+        for (int c2 = 0; c2 < 16; ++c2) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float a = wp[t * 1024 + c2 * 64];
+                const float b0 = xl[c2 * 2 * GW_XCH + (t / 3) * (GW_COLS + 2) + t % 3];
+                const float b1 = xl[c2 * 2 * GW_XCH + (t / 3 + 1) * (GW_COLS + 2) + t % 3];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+            }
+        }
+    }
+    // accumulator register v of lane l: output channel 8 (v / 4) + 4 (l / 32) + v % 4, pixel l % 32
+    const int gx = x0 + j;
+    if (gx >= P.W) return;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int gy = y0 + 2 * wave + r;
+        if (gy >= P.H) continue;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int co = cob * 32 + 8 * (v >> 2) + 4 * kk + (v & 3);
+            if (co < P.cout) gconv_store(P, b, co, gy, gx, acc[r][v]);
+        }
+    }
+}
+
+// weight gradient, stage 1: partial[part][co][ci][9] = sum over the part's tiles of g[b,co,p] * x[b,ci,p + tap];
+// bias_partial[part][co] = sum g (workgroups of input-channel block 0).
+//
+// A GEMM per tap with K = pixels: dW_tap[co][ci] = sum_p G[co][p] X[ci][p + tap], on the exact-fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32 (two pixels per instruction; the fp32 MFMA is an fmaf chain, bitwise: MI355X_MICROARCH.md) -- lane l
+// supplies G[co = l % 32][pixel pair member l / 32] once per pixel pair and the nine shifted X[ci = l % 32] values, nine
+// 32 x 32 accumulators (144 registers) per wave.  A workgroup (4 waves) owns a block of 32 output x 32 input channels and the
+// tiles t = part, part + parts, ... of 8 x 32 pixels; wave w takes the tile rows 2w, 2w + 1.  The X halo tile (32 channels x
+// 10 x 34, zero outside the image and for channels >= cin) and the G tile (32 x 8 x 32, zero outside the image) go through LDS,
+// channel strides padded to odd word counts (341 / 257: the 32 lanes of a read hit 32 banks); 76.5 KB, so two workgroups
+// share a CU and one stages while the other multiplies.  The four waves' accumulators are summed in wave order through LDS.
+// grid (ci blocks * co blocks, parts), 256 threads.
 struct GWgradP {
     const float* x; long long xbs; int cin;
     const float* g; long long gbs; int cout;
     int B, H, W, parts;
     float* partial; float* bias_partial;
 };
-__global__ __launch_bounds__(256) void gwgrad_kernel(const GWgradP P)
+constexpr int GW_LDS_BYTES = 32 * (GW_XCH + GW_GCH) * 4;      // 76,544
+static_assert(32 * (GW_XCH + GW_GCH) >= 9 * 1024 + 256, "the final reduction reuses the tile images");
+
+__global__ __launch_bounds__(256, 2) void gwgrad_mfma_kernel(const GWgradP P)
+{
+    extern __shared__ __attribute__((aligned(16))) float gw_lds[];
+    float* xs = gw_lds;
+    float* gs = gw_lds + 32 * GW_XCH;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, m = lane & 31, kk = lane >> 5;
+    const int nci = (P.cin + 31) / 32;
+    const int cib = (int)blockIdx.x % nci, cob = (int)blockIdx.x / nci, part = blockIdx.y;
+    const int tilesX = (P.W + GW_COLS - 1) / GW_COLS, tilesY = (P.H + GW_ROWS - 1) / GW_ROWS;
+    const int ntiles = P.B * tilesY * tilesX;
+    const long long HW = (long long)P.H * P.W;
+    gf32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+    float bsum = 0.f;
+    for (int tile = part; tile < ntiles; tile += P.parts) {
+        const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY, b = tile / (tilesX * tilesY);
+        const int x0 = tx * GW_COLS, y0 = ty * GW_ROWS;
+        __syncthreads();                               // the previous tile's reads are done
+        gstage_x<4>(xs, gchan_rsrc(P.x + (long long)b * P.xbs + (long long)cib * 32 * HW, P.cin - cib * 32, HW), y0, x0, P.H, P.W, (int)HW, tid);
+        gstage_g<4>(gs, GW_GCH, gchan_rsrc(P.g + (long long)b * P.gbs + (long long)cob * 32 * HW, P.cout - cob * 32, HW), y0, x0, P.H, P.W, (int)HW, tid);
+        __syncthreads();
+        const float* xl = xs + m * GW_XCH + kk;
+        const float* gl = gs + m * GW_GCH + kk;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = 2 * wave + r;
+#pragma unroll 4
+            for (int xp = 0; xp < GW_COLS / 2; ++xp) {
+                const float a = gl[y * GW_COLS + 2 * xp];
+                bsum += a;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float bv = xl[(y + t / 3) * (GW_COLS + 2) + 2 * xp + t % 3];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // the four waves' sums in wave order (fixed: bitwise reproducible), then out: accumulator register v of lane l is
+    // dW[co = 8 (v / 4) + 4 (l / 32) + v % 4][ci = l % 32]
+    float* red = gw_lds;
+    float* bred = gw_lds + 9 * 1024;
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int i = (t * 16 + v) * 64 + lane;
+                    red[i] = (w ? red[i] : 0.f) + acc[t][v];
+                }
+            bred[wave * 64 + lane] = bsum;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * 1024; i += 256) {
+        const int t = i >> 10, v = (i >> 6) & 15, l = i & 63;
+        const int co = cob * 32 + 8 * (v >> 2) + 4 * (l >> 5) + (v & 3), ci = cib * 32 + (l & 31);
+        if (co < P.cout && ci < P.cin) P.partial[(((long long)part * P.cout + co) * P.cin + ci) * 9 + t] = red[i];
+    }
+    if (cib == 0 && tid < 32 && cob * 32 + tid < P.cout) {
+        float sb = 0.f;
+        for (int w = 0; w < 4; ++w) sb += bred[w * 64 + tid] + bred[w * 64 + 32 + tid];
+        P.bias_partial[(long long)part * P.cout + cob * 32 + tid] = sb;
+    }
+}
+// the same partial sums for convs with fewer than 16 channels on a side (the 32 x 32 blocks of the kernel above would be
+// mostly padding): one workgroup per (ci, co, part), fmaf chains, fixed-order LDS tree.  grid (cin, cout, parts), part =
+// a contiguous pixel range.
+__global__ __launch_bounds__(256) void gwgrad_direct_kernel(const GWgradP P)
 {
     __shared__ float red[256];
     const int ci = blockIdx.x, co = blockIdx.y, part = blockIdx.z;
@@ -209,7 +422,7 @@ __global__ void gunshuffle_kernel(const float* dU, const float* U, float* G, int
     }
 }
 // dst[co][ci][t] -> wT[ci][co][8 - t]  for every conv of the table
-struct GPackDesc { long long w_off, t_off; int cout, cin; };
+struct GPackDesc { long long w_off, t_off, pf_off, pt_off; int cout, cin; };   // pf / pt: block-packed copies (-1: none)
 __global__ void gpack_kernel(const float* params, float* wt, const GPackDesc* descs)
 {
     const GPackDesc d = descs[blockIdx.y];
@@ -217,6 +430,24 @@ __global__ void gpack_kernel(const float* params, float* wt, const GPackDesc* de
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
         const int t = e % 9, ci = (e / 9) % d.cin, co = e / (9 * d.cin);
         wt[d.t_off + ((long long)ci * d.cout + co) * 9 + (8 - t)] = params[d.w_off + e];
+    }
+}
+// block-packed weights for gconv_mfma_kernel: [co block][ci block][tap][32 ci][32 co], zero-padded; blockIdx.z = 0: the conv
+// itself (OIHW), 1: its input-gradient conv (W^T with flipped taps: output channels = the conv's inputs)
+__global__ void gpack_blocks_kernel(const float* params, float* wblk, const GPackDesc* descs)
+{
+    const GPackDesc d = descs[blockIdx.y];
+    const bool tr = blockIdx.z == 1;
+    const long long dst = tr ? d.pt_off : d.pf_off;
+    if (dst < 0) return;
+    const int co_n = tr ? d.cin : d.cout, ci_n = tr ? d.cout : d.cin;      // channel counts of the conv being packed
+    const int nci = (ci_n + 31) / 32, n = ((co_n + 31) / 32) * nci * 9 * 1024;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const int k = e & 31, c = (e >> 5) & 31, t = (e >> 10) % 9, blk = e / (9 * 1024);
+        const int co = (blk / nci) * 32 + k, ci = (blk % nci) * 32 + c;
+        float v = 0.f;
+        if (co < co_n && ci < ci_n) v = tr ? params[d.w_off + ((long long)ci * d.cin + co) * 9 + (8 - t)] : params[d.w_off + ((long long)co * d.cin + ci) * 9 + t];
+        wblk[dst + e] = v;
     }
 }
 // dx[b][ci][p] (+)= sum over the out channels of s (skip gradient of the DN head when the image channels broadcast)
@@ -248,7 +479,7 @@ static inline int ew_grid(long long n) { long long g = (n + 255) / 256; return (
 
 GenericNet::~GenericNet()
 {
-    hipFree(wt); hipFree(descs_dev); hipFree(ws); hipFree(wg_partial); hipFree(wg_bias_partial);
+    hipFree(wt); hipFree(wblk); hipFree(descs_dev); hipFree(ws); hipFree(wg_partial); hipFree(wg_bias_partial);
 }
 
 GenericNet* GenericNet::create(const xsd_config& cfg)
@@ -258,9 +489,14 @@ GenericNet* GenericNet::create(const xsd_config& cfg)
     n->nf = cfg.num_filters; n->cin = cfg.in_channels; n->cout = cfg.out_channels; n->blocks = cfg.num_res_blocks;
     n->sr = cfg.kind == XSD_KIND_SR;
     n->nup = n->sr ? cfg.num_upsample : 0;
-    long long off = 0, toff = 0;
+    long long off = 0, toff = 0, boff = 0;
     auto mk = [&](int co, int ci) {
         GConvW c; c.w = off; off += (long long)co * ci * 9; c.b = off; off += co; c.cout = co; c.cin = ci; c.t = toff; toff += (long long)co * ci * 9;
+        c.pf = c.pt = -1;
+        if (c.wide()) {      // block-packed copies for the MFMA kernels: the conv and its input-gradient conv
+            const long long blk = (long long)((co + 31) / 32) * ((ci + 31) / 32) * 9 * 1024;
+            c.pf = boff; boff += blk; c.pt = boff; boff += blk;
+        }
         return c;
     };
     n->first = mk(n->nf, n->cin);
@@ -277,7 +513,7 @@ GenericNet* GenericNet::create(const xsd_config& cfg)
     n->nparams = off;
     n->wt_floats = toff;
     std::vector<GPackDesc> d;
-    auto add = [&](const GConvW& c) { GPackDesc q; q.w_off = c.w; q.t_off = c.t; q.cout = c.cout; q.cin = c.cin; d.push_back(q); };
+    auto add = [&](const GConvW& c) { GPackDesc q; q.w_off = c.w; q.t_off = c.t; q.pf_off = c.pf; q.pt_off = c.pt; q.cout = c.cout; q.cin = c.cin; d.push_back(q); };
     add(n->first);
     for (auto& c : n->rdb) add(c);
     add(n->trunk); add(n->last);
@@ -287,11 +523,13 @@ GenericNet* GenericNet::create(const xsd_config& cfg)
     int maxw = 0;
     for (auto& q : d) maxw = std::max(maxw, q.cout * q.cin * 9);
     n->max_w = maxw;
+    n->wblk_floats = boff;
     if (hipMalloc((void**)&n->wt, sizeof(float) * toff) != hipSuccess ||
+        (boff && hipMalloc((void**)&n->wblk, sizeof(float) * boff) != hipSuccess) ||
         hipMalloc((void**)&n->descs_dev, sizeof(GPackDesc) * d.size()) != hipSuccess ||
         hipMemcpy(n->descs_dev, d.data(), sizeof(GPackDesc) * d.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc((void**)&n->wg_partial, sizeof(float) * (size_t)GenericNet::MAX_PARTS * maxw) != hipSuccess ||
-        hipMalloc((void**)&n->wg_bias_partial, sizeof(float) * (size_t)GenericNet::MAX_PARTS * 4 * std::max(n->nf, n->cout)) != hipSuccess) {
+        hipMalloc((void**)&n->wg_bias_partial, sizeof(float) * ((size_t)GenericNet::MAX_PARTS * maxw / 9 + 1)) != hipSuccess) {   // parts * cout <= capacity / (9 cin)
         delete n;
         return nullptr;
     }
@@ -302,6 +540,7 @@ hipError_t GenericNet::pack(const float* dev_params, hipStream_t s)
 {
     params = dev_params;
     hipLaunchKernelGGL(gpack_kernel, dim3(8, ndesc), dim3(256), 0, s, dev_params, wt, reinterpret_cast<const GPackDesc*>(descs_dev));
+    if (wblk) hipLaunchKernelGGL(gpack_blocks_kernel, dim3(32, ndesc, 2), dim3(256), 0, s, dev_params, wblk, reinterpret_cast<const GPackDesc*>(descs_dev));
     packed = true;
     return hipGetLastError();
 }
@@ -364,6 +603,13 @@ hipError_t GenericNet::conv(hipStream_t s, const GConvW& c, bool transposed, con
     else { p.cin = c.cout; p.cout = c.cin; p.w = wt + c.t; p.bias = nullptr; }
     p.a1 = 1.f; p.a2 = 1.f; p.slope = 1.f;
     if (tweak) tweak(&p);
+    if (c.wide() && (long long)H_ * W_ * 32 * 4 < (1ll << 31)) {      // at least 16 channels on both sides: the fp32 matrix instruction (32-bit byte offsets inside a 32-channel block)
+        p.w = wblk + (transposed ? c.pt : c.pf);
+        GCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GM_LDS_BYTES));
+        const int tiles = ((W_ + GW_COLS - 1) / GW_COLS) * ((H_ + GW_ROWS - 1) / GW_ROWS);
+        hipLaunchKernelGGL(gconv_mfma_kernel, dim3(tiles, (p.cout + 31) / 32, B_), dim3(256), GM_LDS_BYTES, s, p);
+        return hipGetLastError();
+    }
     const int tiles = ((W_ + GT - 1) / GT) * ((H_ + GT - 1) / GT);
     hipLaunchKernelGGL(gconv3x3_kernel, dim3(tiles, (p.cout + GCO - 1) / GCO, B_), dim3(256), 0, s, p);
     return hipGetLastError();
@@ -372,11 +618,25 @@ hipError_t GenericNet::conv(hipStream_t s, const GConvW& c, bool transposed, con
 hipError_t GenericNet::wgrad(hipStream_t s, const GConvW& c, const float* x, long long xbs, const float* g, long long gbs, int B_, int H_, int W_, float* grads)
 {
     GWgradP p;
-    const long long N = (long long)B_ * H_ * W_;
-    int parts = (int)std::min<long long>(MAX_PARTS, std::max<long long>(1, N / 2048));
-    p.x = x; p.xbs = xbs; p.cin = c.cin; p.g = g; p.gbs = gbs; p.cout = c.cout; p.B = B_; p.H = H_; p.W = W_; p.parts = parts;
+    p.x = x; p.xbs = xbs; p.cin = c.cin; p.g = g; p.gbs = gbs; p.cout = c.cout; p.B = B_; p.H = H_; p.W = W_;
     p.partial = wg_partial; p.bias_partial = wg_bias_partial;
-    hipLaunchKernelGGL(gwgrad_kernel, dim3(c.cin, c.cout, parts), dim3(256), 0, s, p);
+    // partial-sum buffer: MAX_PARTS parts of the largest conv, so a small conv may use more parts
+    const long long cap = (long long)MAX_PARTS * max_w / ((long long)c.cout * c.cin * 9);
+    int parts;
+    if (c.wide() && (long long)H_ * W_ * 32 * 4 < (1ll << 31)) {
+        const long long tiles = (long long)B_ * ((H_ + GW_ROWS - 1) / GW_ROWS) * ((W_ + GW_COLS - 1) / GW_COLS);
+        const int blocks = ((c.cin + 31) / 32) * ((c.cout + 31) / 32);
+        // enough workgroups for two per CU and a few rounds of them, at least four tiles each
+        parts = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(cap, 2048), std::min<long long>(tiles / 4, (2048 + blocks - 1) / blocks)));
+        p.parts = parts;
+        GCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gwgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS_BYTES));
+        hipLaunchKernelGGL(gwgrad_mfma_kernel, dim3(blocks, parts), dim3(256), GW_LDS_BYTES, s, p);
+    } else {
+        const long long N = (long long)B_ * H_ * W_;
+        parts = (int)std::min<long long>(std::min<long long>(cap, MAX_PARTS), std::max<long long>(1, N / 2048));
+        p.parts = parts;
+        hipLaunchKernelGGL(gwgrad_direct_kernel, dim3(c.cin, c.cout, parts), dim3(256), 0, s, p);
+    }
     const int n = c.cout * c.cin * 9;
     hipLaunchKernelGGL(gwgrad_reduce_kernel, dim3((std::max(n, c.cout) + 255) / 256), dim3(256), 0, s, wg_partial, wg_bias_partial, parts, c.cout, c.cin,
                        grads + c.w, grads + c.b);
