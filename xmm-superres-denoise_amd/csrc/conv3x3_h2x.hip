@@ -409,7 +409,11 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
         // +15 % time (1.394 -> 1.603 ms per launch), the weight gradient beside it -7 % (power).  ONE MFMA wave per SIMD with
         // three tile rows (12 x 32 tile, 4 + 4 waves, 256 registers, no spills) and its reads interleaved one behind each MFMA --
         // the configuration a flag-synchronised ring would need: +9 % time (1.415 -> 1.546 ms; round 2 measured +8.6 % for four
-        // rows without the interleave): a lone in-order wave reaches 48 cycles per MFMA here, not 32.  None adopted.)
+        // rows without the interleave): a lone in-order wave reaches 48 cycles per MFMA here, not 32.  The weight pieces issued by
+        // the OLDER MFMA wave of each SIMD (it idles ~2.5k cycles at the barrier) two half-steps ahead into a third weight buffer,
+        // the staging waves' queue holding input loads only: +2.1 ... +3.3 % time -- the pieces' issue is hidden where it is,
+        // and the younger wave's walk grows beside a partner that issues vector-memory instructions.  The epilogue's trailing
+        // vmcnt(0) removed: no change (the compact-mask stores it waits for are not exposed).  None adopted.)
         load_x(0, 0, xf[0]);
         load_w(0, wf[0]);
         load_x(1, 0, xf[1]);

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
         load_w(0, wf[0]);
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
-            const int dx = s >> 2, ir = s & 3;
+            const int ir = s & 3;                                 // column dx = s >> 2
             const int irn = (s + 1) & 3, dxn = (s + 1) >> 2;
             if (s + 1 < 12) load_x(irn, dxn, xf[(s + 1) & 1]);
             if (ir >= 1) mac(1, wf[(ir - 1) & 1], xf[s & 1]);      // output row 1, tap (dy = ir - 1, dx)
