@@ -5,8 +5,8 @@
 // configuration (32 filters, one image channel, res/configs/models.toml).  Every other configuration runs here, in exact fp32
 // (the math mode of xsd_set_math does not apply), on NCHW tensors like the reference's: convs with at least 16 channels on
 // both sides on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32, an fmaf chain: gconv_mfma_kernel, gwgrad_mfma_kernel),
-// narrower ones (the image-side convs; every conv of an 8-filter net) as direct convolutions on the vector ALUs.  Same C ABI, same flat parameter layout, same
-// backward stages as the MFMA path (xsd_engine.hip dispatches on the configuration).
+// narrower ones (the image-side convs; every conv of an 8-filter net) as direct convolutions on the vector ALUs.  Same C
+// ABI, same flat parameter layout, same backward stages as the MFMA path (xsd_engine.hip dispatches on the configuration).
 //
 // Layout.  torch.cat of the dense block (rrdb_blocks.py:49-52) is a channel PREFIX of one slab [B][5 nf][H][W] per dense
 // block: conv_k reads channels [0, k nf) and writes [k nf, (k+1) nf); conv5 of a block writes block 0 of the next slab with
@@ -209,9 +209,34 @@ __global__ __launch_bounds__(256, 2) void gconv_mfma_kernel(const GConvP P)     
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
+    // this thread's 43 elements of the X halo tile: byte offset inside a 32-channel block (fails the range check outside the image)
+    // and LDS word, the same for every block of input channels -- computed once, kept in registers
+    constexpr int PX = (GW_ROWS + 2) * (GW_COLS + 2), NX = 32 * PX, KX = (NX + 255) / 256;
+    int xoff[KX], xli[KX];
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        const int i = tid + 256 * k;
+        const int c = i / PX, r = i - c * PX, hy = r / (GW_COLS + 2), hx = r - hy * (GW_COLS + 2);
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = i < NX && (unsigned)gy < (unsigned)P.H && (unsigned)gx < (unsigned)P.W;
+        xoff[k] = ok ? (c * (int)HW + gy * P.W + gx) * 4 : (int)0x80000000;
+        xli[k] = i < NX ? i + c : 32 * GW_XCH - 1;        // c * GW_XCH + r; past the tile: the last padding word
+    }
     for (int cib = 0; cib < nci; ++cib) {
         __syncthreads();
-        gstage_x<11>(xs, gchan_rsrc(xb + (long long)cib * 32 * HW, P.cin - cib * 32, HW), y0, x0, P.H, P.W, (int)HW, tid);
+        {
+            const __amdgpu_buffer_rsrc_t rs = gchan_rsrc(xb + (long long)cib * 32 * HW, P.cin - cib * 32, HW);
+#pragma unroll
+            for (int k0 = 0; k0 < KX; k0 += 22) {        // 22 requests in flight per thread
+                float v[22];
+#pragma unroll
+                for (int q = 0; q < 22; ++q)
+                    if (k0 + q < KX) v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, xoff[k0 + q], 0, 0));
+#pragma unroll
+                for (int q = 0; q < 22; ++q)
+                    if (k0 + q < KX) xs[xli[k0 + q]] = v[q];
+            }
+        }
         const float4* wsrc = reinterpret_cast<const float4*>(P.w + ((long long)cob * nci + cib) * (9 * 1024));
         for (int i = tid; i < 9 * 256; i += 256) reinterpret_cast<float4*>(wl)[i] = wsrc[i];
         __syncthreads();
