@@ -138,9 +138,10 @@ constexpr int GM_LDS_BYTES = (32 * GW_XCH + 9 * 1024) * 4;    // 80,512
 
 // Tile staging of the matrix-instruction kernels.  Loads are BUFFER loads against a descriptor of the (at most 32) channels
 // being staged: channels past the tensor fail the hardware range check and read as zero, pixels outside the image get an
-// offset that fails it too -- no select on the data, no access outside the tensor.  A thread requests GS_CHUNK elements
-// before it writes the first to LDS (memory-level parallelism; one element at a time is a round trip each; the weight
-// gradient with its 144 accumulator registers affords 4, the conv 11).
+// offset that fails it too -- no select on the data, no access outside the tensor.  A thread requests several elements
+// before it writes the first to LDS (memory-level parallelism; one element at a time is a round trip each): the weight
+// gradient with its 144 accumulator registers affords GS_CHUNK = 4 and recomputes the offsets per tile; the conv, whose tile
+// is fixed per workgroup, keeps its 43 offsets in registers and has 22 requests in flight.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t gchan_rsrc(const float* base, int nch, long long HW)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)((long long)(nch < 32 ? nch : 32) * HW * 4), 0x00020000);
