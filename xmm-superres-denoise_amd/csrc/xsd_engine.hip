@@ -631,9 +631,9 @@ extern "C" {
 
 const char* xsd_last_error(void) { return g_err.c_str(); }
 #ifdef XSD_DIAG
-const char* xsd_version(void) { return "xsd-hip gfx950 r2 (diagnostic variant)"; }
+const char* xsd_version(void) { return "xsd-hip gfx950 r3 (diagnostic variant)"; }
 #else
-const char* xsd_version(void) { return "xsd-hip gfx950 r2"; }
+const char* xsd_version(void) { return "xsd-hip gfx950 r3"; }
 #endif
 
 int xsd_create(const xsd_config* cfg, xsd_engine** out)
