@@ -161,9 +161,11 @@ int xsd_image_upsample(const float* dev_in, float* dev_out, int N, int H, int W,
 int xsd_profile_enable(xsd_engine* e, int enable);
 int xsd_profile_read(xsd_engine* e, int klass, double* total_ms, int64_t* launches, double* total_flop, double* total_bytes);
 
-/* Diagnostic only: accumulated shader-cycle stamps of the conv kernel's phases
- * [0] prologue, [1] prefetch issue, [2] MFMA loop, [3] epilogue, [4] wait+barrier, [5] split+LDS write+barrier, [6] items. */
-int xsd_debug_stamps(xsd_engine* e, int enable, unsigned long long* out8);
+/* Diagnostic only: accumulated shader-cycle stamps of the kernels' phases (32 slots; read with enable = 0).  Conv:
+ * [0] prologue, [1] prefetch issue, [2] MFMA loop, [3] epilogue, [4] wait+barrier, [5] split+LDS write+barrier, [6] items,
+ * [7] s_memrealtime ticks, [8..12] staging wave, [13..15] youngest MFMA wave; weight gradient: [16] staging rounds,
+ * [17] MFMA walk, [18] MFMA wave at the barrier, [19] staging wave at the barrier, [21] tiles. */
+int xsd_debug_stamps(xsd_engine* e, int enable, unsigned long long* out32);
 /* Diagnostic only: hipOccupancyMaxActiveBlocksPerMultiprocessor of the split forward conv kernel at a dynamic LDS size. */
 int xsd_debug_occupancy(int lds_bytes);
 /* Diagnostic only: wall time (ms) of a grid of `grid` workgroups that each sleep `us` microseconds holding `lds_bytes` of LDS

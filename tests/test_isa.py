@@ -22,6 +22,18 @@ def test_role_split_conv_counted_loads():
     assert chk.main() in (None, 0)
 
 
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="hipcc not available")
+def test_diagnostic_build_keeps_the_counted_loads(monkeypatch):
+    """The diagnostic library (`make diag`: in-kernel phase stamps; tools/stamps*.py) is what the cycle
+    analysis rests on, so it has to run the same staging loops.  Round 3 found that it had not: run-time ablation flags and
+    branched stamps inside the staging loops made hipcc copy in-flight load registers (the weight gradients' first tile per
+    workgroup was staged from registers the loads had not reached: non-finite gradients at full size).  Ablations are
+    compile-time now (-DXSD_ABL=n) and the staging stamps branch-free; this holds the -DXSD_DIAG code to the same check."""
+    import check_async_loads as chk
+    monkeypatch.setenv("XSD_CHECK_FLAGS", "-DXSD_DIAG")
+    assert chk.main() in (None, 0)
+
+
 def test_checker_rejects_broken_loops():
     """the checker itself: a copy of a destination while the load is in flight, a foreign vmem op, a wrong count"""
     import check_async_loads as chk

@@ -10,7 +10,7 @@ x = torch.rand(B,1,512,512,device='cuda')
 with torch.no_grad():
     m(x); torch.cuda.synchronize()
     eng = m._engine
-    out = (ctypes.c_uint64*16)()
+    out = (ctypes.c_uint64*32)()
     eng.L.xsd_debug_stamps(eng.h, 1, None)
     t0=torch.cuda.Event(enable_timing=True); t1=torch.cuda.Event(enable_timing=True)
     t0.record(); m(x); t1.record(); torch.cuda.synchronize()
@@ -23,7 +23,7 @@ for n,c in zip(names,v[:6]): print(f'  {n:24s} {c/max(v[6],1):10.0f} cycles/item
 if v[7]: print(f'  in-kernel clock (stamped cycles / s_memrealtime at 100 MHz): {tot/v[7]*0.1:.3f} GHz')
 if any(v[8:13]):
     print('  staging wave 0 (role-split kernel):')
-    for n,c in zip(['input rounds (incl. data waits)','wait for DMA pieces','barrier','of the input rounds: counted data waits','descriptors + DMA issue'],v[8:13]): print(f'  {n:24s} {c/max(v[6],1):10.0f} cycles/item')
+    for n,c in zip(['descriptors, weight DMA issue, input rounds','wait for the DMA pieces','barrier','of the rounds: inside the counted data waits','cursor + tile offsets of the next half-steps'],v[8:13]): print(f'  {n:24s} {c/max(v[6],1):10.0f} cycles/item')
 if any(v[13:16]):
     print('  youngest MFMA wave (role-split kernel):')
     for n,c in zip(['MFMA loop','epilogue','wait+barrier1'],v[13:16]): print(f'  {n:24s} {c/max(v[6],1):10.0f} cycles/item')

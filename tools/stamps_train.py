@@ -13,7 +13,7 @@ x = torch.rand(B, 1, 512, 512, device='cuda'); t = torch.rand(B, 1, 512, 512, de
 tr = DataParallelTrainer(m)
 tr.train_step(x, t); torch.cuda.synchronize()
 eng = tr.engine
-out = (ctypes.c_uint64 * 16)()
+out = (ctypes.c_uint64 * 32)()
 eng.L.xsd_debug_stamps(eng.h, 1, None)
 t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
 t0.record(); tr.train_step(x, t); t1.record(); torch.cuda.synchronize()
@@ -24,7 +24,9 @@ names = ['prologue', 'prefetch issue', 'MFMA loop', 'epilogue', 'wait+barrier1',
 tot = sum(v[:6])
 print(' conv: half-steps', v[6])
 for n, c in zip(names, v[:6]): print(f'  {n:52s} {c / max(v[6], 1):10.0f} cycles/item  {100 * c / max(tot, 1):5.1f}%')
-wn = ['issue loads | staging rounds (role-split)', 'MFMA loop', 'barrier1 | MFMA wave at barrier', 'wait loads+split+write | staging wave at barrier', 'barrier2']
-tot = sum(v[8:13])
-print(' wgrad: tiles', v[13])
-for n, c in zip(wn, v[8:13]): print(f'  {n:52s} {c / max(v[13], 1):10.0f} cycles/tile  {100 * c / max(tot, 1):5.1f}%')
+wn = ['staging rounds', 'MFMA walk', 'MFMA wave at the barrier', 'staging wave at the barrier']
+print(' wgrad: tiles', v[21])
+for n, c in zip(wn, v[16:20]): print(f'  {n:52s} {c / max(v[21], 1):10.0f} cycles/tile')
+if any(v[8:16]):
+    print(' conv staging wave / youngest MFMA wave (cycles per half-step):')
+    for n, c in zip(['input rounds', 'wait for DMA pieces', 'barrier', 'counted data waits', 'bookkeeping', 'youngest: MFMA loop', 'youngest: epilogue', 'youngest: barrier'], v[8:16]): print(f'  {n:52s} {c / max(v[6], 1):10.0f}')

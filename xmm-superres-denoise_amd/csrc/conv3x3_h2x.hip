@@ -209,8 +209,9 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
             }
         };
         f32x4 pin[X3_XR] = {};
-#ifdef XSD_DIAG
-        const int abl = P.ablate;     // 16: empty input descriptors (no input traffic); 1: no split (raw registers written);
+#if defined(XSD_DIAG) && defined(XSD_ABL)   // timing experiments: a COMPILE-TIME constant (-DXSD_DIAG -DXSD_ABL=n builds; a run-time
+                                                  // value puts the hand-counted loads and waits under branches hipcc cannot keep exact)
+        constexpr int abl = XSD_ABL;     // 16: empty input descriptors (no input traffic); 1: no split (raw registers written);
                                       // 2: no input LDS writes; 4: no input loads and no counted waits at all
 #else
         constexpr int abl = 0;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
         TileXY t2 = t1;
         if (items > 2 && n2.k != n1.k) { t2 = tile_of(n2.k); tile_offsets(t2); }
         lds_barrier();                                                                     // (P)
-#ifdef XSD_DIAG   // staging-wave phase stamps, slots 8..12 (X rounds, wait for the DMA pieces, barrier, -, descriptors + DMA issue)
+#ifdef XSD_DIAG   // staging-wave phase stamps, slots 8..12: [8] descriptors + weight DMA issue + X rounds, [9] wait for the DMA pieces, [10] barrier, [11] of [8]: inside the counted data waits, [12] cursor / tile offsets of the next half-steps (between the barrier and the loop top)
         unsigned long long lst[5] = {0, 0, 0, 0, 0};
         unsigned long long lt0 = __builtin_readcyclecounter();
         const bool lstamp = P.dbg != nullptr;

@@ -171,8 +171,9 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
             d[2] = (int)bytes; d[3] = 0x00020000;
             return d;
         };
-#ifdef XSD_DIAG
-        const int abl = P.ablate;     // 16: empty input descriptors (no input traffic); 1: no split (raw registers written);
+#if defined(XSD_DIAG) && defined(XSD_ABL)   // timing experiments: a COMPILE-TIME constant (-DXSD_DIAG -DXSD_ABL=n builds; a run-time
+                                                  // value puts the hand-counted loads and waits under branches hipcc cannot keep exact)
+        constexpr int abl = XSD_ABL;     // 16: empty input descriptors (no input traffic); 1: no split (raw registers written);
                                       // 2: no input LDS writes; 4: no input loads and no counted waits at all
 #else
         constexpr int abl = 0;

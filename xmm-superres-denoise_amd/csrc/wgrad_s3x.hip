@@ -86,14 +86,19 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
         asm volatile("" ::: "memory");
     };
 
-#ifdef XSD_DIAG   // phase stamps (diagnostic library only; tools/stamps_train.py): slot 8 staging rounds, 9 MFMA walk, 10 MFMA
-                  // wave at the barrier, 11 staging wave at the barrier, 13 tiles
+#ifdef XSD_DIAG   // phase stamps (diagnostic library only; tools/stamps_train.py): slot 16 staging rounds, 17 MFMA walk, 18 MFMA
+                  // wave at the barrier, 19 staging wave at the barrier, 21 tiles (slots 0-15 belong to the conv kernels)
     unsigned long long st[2] = {0, 0};
     unsigned long long t0 = __builtin_readcyclecounter();
     const bool stamp = P.dbg != nullptr;
 #define V3_TICK(i) do { if (stamp) { const unsigned long long t_ = __builtin_readcyclecounter(); st[i] += t_ - t0; t0 = t_; } } while (0)
 #else
 #define V3_TICK(i) do { } while (0)
+#endif
+#ifdef XSD_DIAG   // staging-wave stamps: branch-free (wgrad_h2x.hip)
+#define V3_LTICK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); st[i] += t_ - t0; t0 = t_; } while (0)
+#else
+#define V3_LTICK(i) do { } while (0)
 #endif
     f32x16 acc[9];
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f}; // staging thread: its 4 channels (lt & 7) of the G tiles it stages
@@ -161,8 +166,9 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
         // columns left / right of the image would alias the neighbouring row: those lanes get the failing offset
         auto x_off = [&](int r, const TileAt& a) { return ((unsigned)(a.x0 - 1 + xhx[r]) < (unsigned)P.W) ? a.xorg + xrel[r] : OOR; };
         auto g_off = [&](int r, const TileAt& a) { return (a.x0 + ggx[r] < P.W) ? a.gorg + grel[r] : OOR; };
-#ifdef XSD_DIAG
-        const int abl = P.ablate;     // 1: no split, 2: no LDS writes (results are garbage: timing experiments only)
+#if defined(XSD_DIAG) && defined(XSD_ABL)   // timing experiments: a COMPILE-TIME constant (-DXSD_DIAG -DXSD_ABL=n builds; a run-time
+                                                  // value puts the hand-counted loads and waits under branches hipcc cannot keep exact)
+        constexpr int abl = XSD_ABL;     // 1: no split, 2: no LDS writes (results are garbage: timing experiments only)
 #else
         constexpr int abl = 0;
 #endif
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
             for (int r = 0; r < V3_G_ROUNDS; ++r) asm_load4(pg[r], g_off(r, a), a.grs);
         }
         lds_barrier();                                                                     // (P)
-        V3_TICK(1);
+        V3_LTICK(1);
 #pragma unroll 1
         for (int k = 0; k < my_tiles; ++k) {
             // tile k+1: registers -> the other buffer; each register is refilled with tile k+2 right after its split
@@ -229,13 +235,13 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
                 asm_load4(pg[r], g_off(r, a), a.grs);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            V3_TICK(0);
+            V3_LTICK(0);
             lds_barrier();
-            V3_TICK(1);
+            V3_LTICK(1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef XSD_DIAG
-        if (stamp && tid == 0) { atomicAdd(&P.dbg[8], st[0]); atomicAdd(&P.dbg[11], st[1]); }
+        if (stamp && tid == 0) { atomicAdd(&P.dbg[16], st[0]); atomicAdd(&P.dbg[19], st[1]); }
 #endif
         // tiles past the end were staged as zeros (empty descriptors): bsum took 0 from them; tile 0 and 1 were counted once each
     } else {
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
             V3_TICK(1);
         }
 #ifdef XSD_DIAG
-        if (stamp && tid == V3_LT) { atomicAdd(&P.dbg[9], st[0]); atomicAdd(&P.dbg[10], st[1]); atomicAdd(&P.dbg[13], (unsigned long long)my_tiles); }
+        if (stamp && tid == V3_LT) { atomicAdd(&P.dbg[17], st[0]); atomicAdd(&P.dbg[18], st[1]); atomicAdd(&P.dbg[21], (unsigned long long)my_tiles); }
 #endif
     }
 

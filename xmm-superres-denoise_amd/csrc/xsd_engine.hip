@@ -973,10 +973,10 @@ int xsd_debug_stamps(xsd_engine* e, int enable, unsigned long long* out16)
 {
     if (!e) return fail(XSD_ERR_ARG, "null engine");
     HIPCHK(hipDeviceSynchronize());
-    if (out16 && e->dbg) HIPCHK(hipMemcpy(out16, e->dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (out16 && e->dbg) HIPCHK(hipMemcpy(out16, e->dbg, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (enable) {
-        if (!e->dbg) HIPCHK(hipMalloc((void**)&e->dbg, 16 * sizeof(unsigned long long)));
-        HIPCHK(hipMemset(e->dbg, 0, 16 * sizeof(unsigned long long)));
+        if (!e->dbg) HIPCHK(hipMalloc((void**)&e->dbg, 32 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(e->dbg, 0, 32 * sizeof(unsigned long long)));
     } else if (e->dbg) { hipFree(e->dbg); e->dbg = nullptr; }
     return XSD_OK;
 }
@@ -1039,6 +1039,7 @@ static int pack_single(const float* dev_w, int cout, int cin, float** fwd, float
 static hipError_t run_conv(xsd_engine* e, ConvParams& p, hipStream_t s)
 {
     p.zero = e->zero_page;
+    p.ablate = e->ablate;      // (0 outside the diagnostic library)
     for (int i = 0; i < (p.n_out > 1 ? p.n_out : p.n_in); ++i) p.wstep[i] = p.wpanel + (long long)i * PANEL_FLOATS;
     if (e->math == 4) {   // test hook: nobody has reported the operands' max |x| -> reduce them here (slots at the end of the array)
         float* t = e->amax + xsd_engine::AMAX_CAP - 32;    // (CAP-16.. belong to the weight-gradient hook, CAP-4 / CAP-3 to pack_single)
@@ -1099,7 +1100,7 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
         wp.B = B; wp.H = H; wp.W = W; wp.tilesX = p.tilesX; wp.tilesY = p.tilesY; wp.n_in = n_in; wp.n_g = 1; wp.nparts = e->nparts;
         for (int i = 0; i < n_in; ++i) wp.x[i] = b.std_in(in_planes[i], 0);
         wp.g[0] = b.std_in(g, 0);
-        wp.partial = e->wg_partial; wp.bias_partial = e->wg_bias_partial; wp.zero = e->zero_page;
+        wp.partial = e->wg_partial; wp.bias_partial = e->wg_bias_partial; wp.zero = e->zero_page; wp.ablate = e->ablate;
         if (e->math == 4) {   // test hook: reduce the operands' max |x| here (slots at the end of the array, after run_conv's)
             float* t = e->amax + xsd_engine::AMAX_CAP - 16;
             err = hipMemsetAsync(t, 0, 8 * sizeof(float), s);
