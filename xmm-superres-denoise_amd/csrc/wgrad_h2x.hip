@@ -35,8 +35,9 @@ constexpr int V3_TH = V3_TH_ROWS;                                     // tile ro
 constexpr int V3_MW = 8;                                              // MFMA waves: the 27 accumulators dealt 4,4,4,3,3,3,3,3
 #ifndef V3_LWAVES
 #define V3_LWAVES 4     // staging waves, one per SIMD, beside two MFMA waves per SIMD (12 waves, 168 registers).  Eight staging
-#endif                  // waves (16 waves, 128 registers; -DV3_LWAVES=8) measured 9 % slower on one device: the staging side is
-                        // bound by the CU's load path (12-13 B/clk), not by vector issue (measured with 4-row tiles).
+#endif                  // waves (16 waves, 128 registers; -DV3_LWAVES=8) measured 9 % slower on one device (with 4-row tiles): the
+                        // staging waves are not the critical path (clean stamps of round 3: they wait ~1.8k cycles per tile at
+                        // the barrier for the younger MFMA wave of their SIMD).
 constexpr int V3_LT = 64 * V3_LWAVES;                                 // staging threads (waves 0 .. V3_LWAVES-1)
 constexpr int V3_THREADS = V3_LT + 64 * V3_MW;                        // 768
 constexpr int V3_HPX = (V3_TH + 2) * HALO_W;                          // 340 halo pixels
