@@ -381,6 +381,9 @@ def test_backward_rejects_mismatched_dy_and_stale_generation():
     ("sr", 8, 1, 1, 1, 2, (1, 9, 11)),       # two pixel-shuffle stages
     ("dn", 64, 3, 3, 2, 1, (2, 70, 133)),    # several tiles per image, 320-channel dense convs, RGB with the skip
     ("sr", 48, 1, 1, 1, 1, (1, 21, 45)),     # matrix-instruction path with partial 32-channel blocks (48 .. 240 inputs, 192-channel shuffle conv), ragged against its 8 x 32 tile
+    ("sr", 64, 1, 1, 1, 1, (2, 19, 37)),     # 64 filters, one image channel: the plane kernels with two planes per tensor (Builder::build_multi), shuffle conv 64 -> 256
+    ("sr", 64, 1, 1, 2, 2, (1, 9, 11)),      # ... two pixel-shuffle stages, two blocks
+    ("dn", 96, 1, 1, 1, 1, (1, 17, 40)),     # three planes per tensor: K-loops of up to 15 planes in launches of five
 ])
 def test_generic_widths_vs_float64_restatement(kind, nf, in_ch, out_ch, blocks, nup, shape):
     """Widths other than the shipped 32 / 1 / 1 (reference constructors take any: generator_rrdb.py:10-54) run on the
@@ -388,6 +391,10 @@ def test_generic_widths_vs_float64_restatement(kind, nf, in_ch, out_ch, blocks, 
     64-, 48- and 16-filter cases), narrower ones as direct convolutions.  Forward, dL/dx and every parameter gradient against a
     float64 evaluation of the reference graph (oracle.torch_forward; the C oracle handles one image channel only), through
     the nn.Module API, L1 loss."""
+    _widths_vs_float64(kind, nf, in_ch, out_ch, blocks, nup, shape)
+
+
+def _widths_vs_float64(kind, nf, in_ch, out_ch, blocks, nup, shape, math=None):
     from collections import OrderedDict
     rng = np.random.default_rng(4242 + nf + in_ch)
     shapes = gc.rrdb_param_shapes(kind, nf, blocks, in_ch=in_ch, out_ch=out_ch, num_upsample=nup)
@@ -408,6 +415,8 @@ def test_generic_widths_vs_float64_restatement(kind, nf, in_ch, out_ch, blocks, 
     l64 = torch.nn.functional.l1_loss(y64, torch.from_numpy(t).double())
     l64.backward()
     m = build_module(kind, blocks, nup, state, nf=nf, in_ch=in_ch, out_ch=out_ch)
+    if math:
+        m.set_math(math)
     xd = torch.from_numpy(x).cuda().requires_grad_(True)
     y = m(xd)
     assert y.shape == tuple(y64.shape)
@@ -422,3 +431,14 @@ def test_generic_widths_vs_float64_restatement(kind, nf, in_ch, out_ch, blocks, 
     # and without autograd (no activations kept: two slabs ping-pong) the same output, bit for bit
     with torch.no_grad():
         assert torch.equal(m(xd.detach()), y.detach())
+
+
+@pytest.mark.parametrize("math", MATHS)
+@pytest.mark.parametrize("kind,nf,blocks,nup,shape", [("dn", 64, 1, 1, (2, 24, 40)), ("sr", 128, 1, 1, (1, 12, 33))])
+def test_wide_plane_nets_in_every_math_mode(kind, nf, blocks, nup, shape, math):
+    """64 / 96 / 128 filters with one image channel run on the 32-filter configuration's own kernels, a feature tensor being
+    2 - 4 planes of 32 channels and a conv's K-loop cut into launches of <= 5 planes that accumulate (csrc/xsd_engine.hip,
+    Builder::build_multi; the dense block's default width is 64, rrdb_blocks.py:23).  Forward, dL/dx and every parameter
+    gradient against float64 in each math mode (the 128-filter SR case: four planes, a 128 -> 512 shuffle conv, K-loops of up
+    to 20 planes)."""
+    _widths_vs_float64(kind, nf, 1, 1, blocks, nup, shape, math=math)

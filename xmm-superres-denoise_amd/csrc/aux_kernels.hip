@@ -293,12 +293,12 @@ __global__ void pack_weights_kernel(const float* params, const PackDesc* descs, 
         const int k = 16 * h + 4 * j + t;
         { // forward: panel = n*ns + s
             const int n = panel / ns, s = panel % ns;
-            const int oc = d.shuffle ? (4 * c + n) : (32 * n + c);
+            const int oc = d.shuffle ? (4 * (32 * (n % (nn / 4)) + c) + n / (nn / 4)) : (32 * n + c);   // shuffle: chunk n = sub-pixel * P + plane
             fwd[d.dst_fwd + e] = W[((long long)oc * d.cin + 32 * s + k) * 9 + tap];
         }
         { // dgrad: panel = s*nn + n
             const int s = panel / nn, n = panel % nn;
-            const int oc = d.shuffle ? (4 * k + n) : (32 * n + k);
+            const int oc = d.shuffle ? (4 * (32 * (n % (nn / 4)) + k) + n / (nn / 4)) : (32 * n + k);
             bwd[d.dst_bwd + e] = d.bwd_scale * W[((long long)oc * d.cin + 32 * s + c) * 9 + (8 - tap)];
         }
     }
@@ -325,12 +325,12 @@ __global__ void pack_weights_s3_kernel(const float* params, const PackDesc* desc
         const int k = 16 * s2 + 8 * h + j;
         {
             const int n = panel / ns, s = panel % ns;
-            const int oc = d.shuffle ? (4 * m + n) : (32 * n + m);
+            const int oc = d.shuffle ? (4 * (32 * (n % (nn / 4)) + m) + n / (nn / 4)) : (32 * n + m);   // shuffle: chunk n = sub-pixel * P + plane
             fwd[d.dst_fwd + e] = W[((long long)oc * d.cin + 32 * s + k) * 9 + tap];
         }
         {
             const int s = panel / nn, n = panel % nn;
-            const int oc = d.shuffle ? (4 * k + n) : (32 * n + k);
+            const int oc = d.shuffle ? (4 * (32 * (n % (nn / 4)) + k) + n / (nn / 4)) : (32 * n + k);
             bwd[d.dst_bwd + e] = d.bwd_scale * W[((long long)oc * d.cin + 32 * s + m) * 9 + (8 - tap)];
         }
     }
@@ -395,11 +395,14 @@ __global__ void pack_edge_kernel(const float* w_first, const float* w_last, floa
     last_bwd[e] = w_last[c * 9 + (8 - tap)];   // dT[p][c] += dy[p+tap'] * W[0][c][8-tap']
 }
 
-// bias of the pixel-shuffle conv in chunk order: out[n*32 + c] = b[4c + n]
-__global__ void pack_shuffle_bias_kernel(const float* b, float* out)
+// bias of the pixel-shuffle conv (4 * 32 P outputs) in chunk order: chunk n = sub-pixel * P + plane q holds the channels
+// 4 (32 q + c) + sub-pixel:  out[n*32 + c] = b[4 (32 q + c) + sub]
+__global__ void pack_shuffle_bias_kernel(const float* b, float* out, int P)
 {
-    const int e = threadIdx.x;
-    if (e < 128) out[e] = b[4 * (e & 31) + (e >> 5)];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 128 * P) return;
+    const int n = e >> 5, c = e & 31;
+    out[e] = b[4 * (32 * (n % P) + c) + n / P];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -602,9 +605,9 @@ hipError_t launch_pack_edge(const float* w_first, const float* w_last, float* ff
     hipLaunchKernelGGL(pack_edge_kernel, dim3(2), dim3(256), 0, s, w_first, w_last, ff, fb, lf, lb);
     return hipGetLastError();
 }
-hipError_t launch_pack_shuffle_bias(const float* b, float* out, hipStream_t s)
+hipError_t launch_pack_shuffle_bias(const float* b, float* out, int planes, hipStream_t s)
 {
-    hipLaunchKernelGGL(pack_shuffle_bias_kernel, dim3(1), dim3(128), 0, s, b, out);
+    hipLaunchKernelGGL(pack_shuffle_bias_kernel, dim3(planes), dim3(128), 0, s, b, out, planes);
     return hipGetLastError();
 }
 hipError_t launch_mask_pad_normalize(const MaskPadParams& p, hipStream_t s)

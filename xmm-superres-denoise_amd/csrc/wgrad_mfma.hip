@@ -201,8 +201,8 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReducePar
         const int j = r % R.n_in;
         const int n = r / R.n_in;
         const int cch = co, ich = ci;
-        const int oc = R.shuffle ? (4 * cch + n) : (32 * n + cch);
-        R.dw[((long long)oc * R.cin_total + (32 * j + ich)) * 9 + tap] = (float)(t * (double)R.scale);
+        const int oc = R.shuffle ? (4 * (32 * R.plane + cch) + n) : (32 * (R.n0 + n) + cch);
+        R.dw[((long long)oc * R.cin_total + (32 * (R.j0 + j) + ich)) * 9 + tap] = (float)(t * (double)R.scale);
     }
     // bias: block 0; the same 16 x (P/16) fixed-order scheme (a serial 256-load chain here used to cost 60 us per launch)
     if (blockIdx.x == 0) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReducePar
             for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
             const int co = threadIdx.x & 31, n = threadIdx.x >> 5;
             const int cch = co;
-            const int oc = R.shuffle ? (4 * cch + n) : (32 * n + cch);
+            const int oc = R.shuffle ? (4 * (32 * R.plane + cch) + n) : (32 * (R.n0 + n) + cch);
             R.db[oc] = (float)(t * (double)R.scale);
         }
     }

@@ -35,7 +35,7 @@ using namespace xsd;
 namespace xsd {
 int debug_conv_occupancy(int lds_bytes);
 float debug_residency_ms(int grid, int threads, int lds_bytes, int us);
-hipError_t launch_pack_shuffle_bias(const float* b, float* out, hipStream_t s);
+hipError_t launch_pack_shuffle_bias(const float* b, float* out, int planes, hipStream_t s);
 }
 
 static thread_local std::string g_err;
@@ -69,7 +69,8 @@ struct ProfRec { hipEvent_t a, b; double flop, bytes; int klass; };
 
 struct xsd_engine {
     xsd_config cfg;
-    GenericNet* generic = nullptr;   // widths other than 32 filters / 1 image channel: exact-fp32 direct-conv kernels (generic_net.hip)
+    GenericNet* generic = nullptr;   // widths the plane kernels do not take (generic_net.hip): filters that are no multiple of 32 or > 128, image channels != 1
+    int planes = 1;                  // num_filters / 32: 32-channel planes per feature tensor (1 = the shipped configuration; 2..4: Builder::build_multi)
     long long nparams = 0;
     // flat-param offsets
     long long first_w = 0, first_b = 0, last_w = 0, last_b = 0;
@@ -93,7 +94,7 @@ struct xsd_engine {
     // math mode 4 (f16x3): max |x| slots; [0] packed forward panels, [1] packed input-gradient panels, [2..] planes of the plan
     float* amax = nullptr;
     int amax_used = 2;
-    static constexpr int AMAX_CAP = 8192;
+    static constexpr int AMAX_CAP = 65536;
     const float* params = nullptr; // borrowed (bias reads)
     bool packed = false;
     // workspace
@@ -331,7 +332,7 @@ struct Builder {
     }
     // wgrad + fixed-order reduce into the flat gradient vector
     void wgrad_launch(std::vector<Launch>& ops, int level, const std::vector<PlaneIn>& xs, const std::vector<PlaneIn>& gs,
-                      const ConvW& cw, float scale)
+                      const ConvW& cw, float scale, int j0 = 0, int n0 = 0, int plane = 0)
     {
         xsd_engine* eng = e;
         WgradParams wp;
@@ -349,7 +350,7 @@ struct Builder {
         WgradReduceParams rp;
         memset(&rp, 0, sizeof(rp));
         rp.nparts = wp.nparts; rp.n_in = wp.n_in; rp.n_g = wp.n_g; rp.cin_total = cw.cin; rp.cout_total = cw.cout;
-        rp.shuffle = cw.shuffle; rp.scale = scale;
+        rp.shuffle = cw.shuffle; rp.scale = scale; rp.j0 = j0; rp.n0 = n0; rp.plane = plane;
         const long long w_off = cw.w_off, b_off = cw.b_off;
         const double px = (double)wp.B * wp.H * wp.W;
         const double flop = 2.0 * 9 * 32 * 32 * wp.n_in * wp.n_g * px;
@@ -369,6 +370,7 @@ struct Builder {
     // ---------------------------------------------------------------------------------------------------------
     void build()
     {
+        if (e->planes > 1) { build_multi(); return; }
         xsd_engine* eng = e;
         const int blocks = e->cfg.num_res_blocks;
         const bool sr = e->cfg.kind == XSD_KIND_SR;
@@ -601,6 +603,311 @@ struct Builder {
             });
         }
     }
+
+    // ---------------------------------------------------------------------------------------------------------
+    // Wide nets: num_filters = 32 P (P = 2..4), one image channel -- the dense block's own default width is 64
+    // (rrdb_blocks.py:23).  A feature tensor is P planes of 32 channels in torch.cat's channel order; a conv with 32 a
+    // inputs and 32 b outputs is b output chunks, each ONE K-loop over the a input planes, cut into launches of <= 5 planes: the
+    // first launch carries the bias, the later ones add to the plane it wrote (`accumulate` epilogue), the last one carries the
+    // layer's epilogue (residuals, LeakyReLU, masks).  LeakyReLU' masks are read from the activation planes (the compact mask
+    // words have no epilogue variant with `accumulate`).  Same kernels, same packed panels ([chunk][plane] / [plane][chunk]
+    // order, pack_weights*_kernel), same backward stages and flat gradient layout as build().
+    typedef std::vector<float*> Tensor;
+    void build_multi()
+    {
+        xsd_engine* eng = e;
+        const int P = e->planes;
+        const int blocks = e->cfg.num_res_blocks;
+        const bool sr = e->cfg.kind == XSD_KIND_SR;
+        const int nup = sr ? e->cfg.num_upsample : 0;
+        std::vector<Launch>& F = e->fwd_ops;
+        F.clear();
+        e->bwd_stages.assign(blocks + 2, {});
+        const float* edge = e->pk_edge;      // [first_fwd | first_bwd | last_fwd | last_bwd][plane][288]
+        auto first_fwd = [&](int q) { return edge + 288 * q; };
+        auto first_bwd = [&](int q) { return edge + 288 * (P + q); };
+        auto last_fwd = [&](int q) { return edge + 288 * (2 * P + q); };
+        auto last_bwd = [&](int q) { return edge + 288 * (3 * P + q); };
+
+        auto alloc_t = [&](int level) { Tensor t(P); for (auto& p : t) p = alloc(level); return t; };
+        auto release_t = [&](const Tensor& t, int level, bool force = false) { for (float* p : t) release(p, level, force); };
+        auto planes_of = [&](const Tensor& t, int level) { std::vector<PlaneIn> v; for (float* p : t) v.push_back(std_in(p, level)); return v; };
+        auto out_desc = [&](float* p, int level) { OutDesc o = conv_base(level).out[0]; std_out(o, p, level); return o; };
+        // one output plane: the K-loop over `ins` with the panels `pan` (one per input plane), <= 5 planes per launch
+        auto kloop = [&](std::vector<Launch>& ops, int level, const std::vector<PlaneIn>& ins, const std::vector<const float*>& pan,
+                         const OutDesc& fin, bool bias_from_params, long long bias_off, const float* bias_ptr) {
+            const int n = (int)ins.size();
+            for (int base = 0; base < n; base += 5) {
+                const int cnt = std::min(5, n - base);
+                const bool first = base == 0, last = base + cnt >= n;
+                ConvParams p = conv_base(level);
+                p.n_in = cnt; p.n_out = 1;
+                for (int k = 0; k < cnt; ++k) { p.in[k] = ins[base + k]; p.wstep[k] = pan[base + k]; }
+                p.wpanel = p.wstep[0];
+                OutDesc& o = p.out[0];
+                if (last) o = fin;
+                else { o.p = fin.p; o.ps = fin.ps; o.rs = fin.rs; o.bs = fin.bs; o.a1 = fin.a1; }   // partial sums carry the final scale
+                o.accumulate = first ? 0 : 1;
+                if (first) p.bias = bias_ptr;
+                ops.push_back(conv_launch(p, first && bias_from_params, bias_off));
+            }
+        };
+        // weight gradient of one conv: per output chunk, the input planes in groups of <= 5
+        auto wgrad_all = [&](std::vector<Launch>& ops, int level, const std::vector<PlaneIn>& xs, const Tensor& g, const ConvW& cw, float scale) {
+            for (int q = 0; q < P; ++q)
+                for (int base = 0; base < (int)xs.size(); base += 5) {
+                    std::vector<PlaneIn> grp(xs.begin() + base, xs.begin() + std::min<size_t>(xs.size(), base + 5));
+                    wgrad_launch(ops, level, grp, {std_in(g[q], level)}, cw, scale, base, q, 0);
+                }
+        };
+        // 32P -> 1 edge conv over the planes of `f`: partial sums chained through `tmp`; `fin` fills in the last launch
+        auto reduce_chain = [&](std::vector<Launch>& ops, const Tensor& f, int level, const std::function<const float*(int)>& w, long long bias_off,
+                                float* tmp, const std::function<bool(EdgeReduceParams&)>& fin) {
+            for (int q = 0; q < P; ++q) {
+                EdgeReduceParams p; memset(&p, 0, sizeof(p));
+                p.B = B; p.H = H << level; p.W = W << level; p.f = f[q]; p.w = w(q);
+                const bool first = q == 0, last = q == P - 1;
+                ops.push_back([eng, p, first, last, bias_off, tmp, fin](hipStream_t s) mutable {
+                    if (first && bias_off >= 0) p.bias = eng->params + bias_off;
+                    if (!first) p.addto = tmp;
+                    if (last) { if (!fin(p)) return hipSuccess; }
+                    else p.y = tmp;
+                    return launch_edge_reduce(p, s);
+                });
+            }
+        };
+
+        struct RdbActM { Tensor xin, xs[4], out; };
+        std::vector<RdbActM> acts(blocks * 3);
+        std::vector<Tensor> rin(blocks + 1);
+
+        // ---- forward ------------------------------------------------------------------------------------------
+        Tensor fea = alloc_t(0);
+        for (int q = 0; q < P; ++q) { // conv_first (generator_rrdb.py:67), 32 output channels per launch
+            EdgeExpandParams p; memset(&p, 0, sizeof(p));
+            p.B = B; p.H = H; p.W = W; p.out = fea[q]; p.w = first_fwd(q); p.mslope = 1.f;
+            const long long boff = e->first_b + 32 * q;
+            F.push_back([eng, p, boff](hipStream_t s) mutable { p.s = eng->b_x; p.bias = eng->params + boff; return launch_edge_expand(p, s); });
+        }
+        Tensor cur = fea;
+        for (int i = 0; i < blocks; ++i) {
+            rin[i] = cur;
+            for (int r = 0; r < 3; ++r) {
+                RdbActM& a = acts[i * 3 + r];
+                a.xin = cur;
+                for (int c = 0; c < 5; ++c) {
+                    const ConvW& cw = e->rdb[(i * 3 + r) * 5 + c];
+                    const int ns = (c + 1) * P;
+                    std::vector<PlaneIn> ins;
+                    for (int t = 0; t <= c; ++t) for (float* pl : (t == 0 ? a.xin : a.xs[t - 1])) ins.push_back(std_in(pl, 0));
+                    Tensor o = alloc_t(0);
+                    for (int q = 0; q < P; ++q) {
+                        std::vector<const float*> pan;
+                        for (int k = 0; k < ns; ++k) pan.push_back(fwdp(cw.fwd_off + ((long long)q * ns + k) * PANEL_FLOATS));
+                        OutDesc fin = out_desc(o[q], 0);
+                        if (c < 4) fin.slope = 0.2f;                                                   // rrdb_blocks.py:38-52
+                        else {
+                            fin.a1 = 0.2f; fin.e1 = a.xin[q]; fin.s1 = 1.f;                            // x5*0.2 + x   (:54)
+                            if (r == 2) { fin.a2 = 0.2f; fin.e2 = rin[i][q]; fin.s2 = 1.f; }           // out*0.2 + x (:70)
+                        }
+                        kloop(F, 0, ins, pan, fin, true, cw.b_off + 32 * q, nullptr);
+                    }
+                    if (c < 4) a.xs[c] = o; else a.out = o;
+                }
+                for (int k = 0; k < 4; ++k) release_t(a.xs[k], 0);
+                if (r > 0) release_t(a.xin, 0);
+                cur = a.out;
+            }
+            if (i > 0) release_t(rin[i], 0);
+        }
+        rin[blocks] = cur;
+        Tensor T = alloc_t(0);
+        for (int q = 0; q < P; ++q) { // fea + trunk_conv(rrdb(fea)) (generator_rrdb.py:68-69)
+            std::vector<const float*> pan;
+            for (int k = 0; k < P; ++k) pan.push_back(fwdp(e->trunk.fwd_off + ((long long)q * P + k) * PANEL_FLOATS));
+            OutDesc fin = out_desc(T[q], 0);
+            fin.e1 = fea[q]; fin.s1 = 1.f;
+            kloop(F, 0, planes_of(cur, 0), pan, fin, true, e->trunk.b_off + 32 * q, nullptr);
+        }
+        release_t(cur, 0);
+        release_t(fea, 0);
+
+        std::vector<Tensor> U(nup);
+        Tensor H1;
+        const int lo = nup; // output level
+        if (sr) {
+            Tensor feat = T;
+            for (int u = 0; u < nup; ++u) { // upsampling: conv 32P -> 128P, LeakyReLU(0.01), PixelShuffle(2) (generator_rrdb.py:93-99)
+                U[u] = alloc_t(u + 1);
+                for (int q = 0; q < P; ++q)
+                    for (int sub = 0; sub < 4; ++sub) {           // chunk n = sub * P + q holds the channels 4 (32 q + c) + sub
+                        const int n = sub * P + q;
+                        std::vector<const float*> pan;
+                        for (int k = 0; k < P; ++k) pan.push_back(fwdp(e->up[u].fwd_off + ((long long)n * P + k) * PANEL_FLOATS));
+                        OutDesc fin = conv_base(u).out[0];
+                        shuf_out(fin, U[u][q], u, sub);
+                        fin.slope = 0.01f;
+                        kloop(F, u, planes_of(feat, u), pan, fin, false, 0, e->pk_sbias + e->up[u].sbias_off + 32 * n);
+                    }
+                release_t(feat, u);
+                feat = U[u];
+            }
+            H1 = alloc_t(lo);
+            for (int q = 0; q < P; ++q) { // lrelu(HRconv(fea)) (generator_rrdb.py:107)
+                std::vector<const float*> pan;
+                for (int k = 0; k < P; ++k) pan.push_back(fwdp(e->hr.fwd_off + ((long long)q * P + k) * PANEL_FLOATS));
+                OutDesc fin = out_desc(H1[q], lo);
+                fin.slope = 0.2f;
+                kloop(F, lo, planes_of(feat, lo), pan, fin, true, e->hr.b_off + 32 * q, nullptr);
+            }
+            release_t(feat, lo);
+        }
+        float* pre = train ? alloc1(lo) : nullptr;
+        float* ytmp = alloc1(lo);
+        const Tensor& headf = sr ? H1 : T;
+        // conv_last (+x for DN) + clamp, clamp (generator_rrdb.py:107-108,132-135; model.py:49)
+        reduce_chain(F, headf, lo, last_fwd, e->last_b, ytmp, [eng, pre, sr](EdgeReduceParams& p) {
+            p.skip = sr ? nullptr : eng->b_x; p.pre = pre; p.clamp01 = 1; p.y = eng->b_y; return true; });
+        if (!train) return;
+
+        // ---- backward -----------------------------------------------------------------------------------------
+        float* dpre = alloc1(lo);
+        Tensor dT = alloc_t(0);
+        { // stage 0: output head
+            std::vector<Launch>& S = e->bwd_stages[0];
+            const long long npx = (long long)B * (H << lo) * (W << lo);
+            S.push_back([eng, pre, dpre, npx](hipStream_t s) { return launch_clamp_bwd(pre, eng->b_dy, dpre, npx, s); });
+            for (int q = 0; q < P; ++q) { // conv_last weight grad, 32 input channels per launch (the bias gradient is the same sum every time)
+                EdgeWgradParams p; memset(&p, 0, sizeof(p));
+                p.B = B; p.H = H << lo; p.W = W << lo; p.f = headf[q]; p.s = dpre; p.nblocks = EDGE_WGRAD_BLOCKS;
+                const long long wo = e->last_w + 288 * q, bo = e->last_b;
+                S.push_back([eng, p, wo, bo](hipStream_t s) mutable {
+                    p.partial = eng->edge_partial; return launch_edge_wgrad(p, 1, eng->b_grads + wo, eng->b_grads + bo, s);
+                });
+            }
+            if (!sr) {
+                for (int q = 0; q < P; ++q) {
+                    EdgeExpandParams p; memset(&p, 0, sizeof(p));
+                    p.B = B; p.H = H; p.W = W; p.s = dpre; p.w = last_bwd(q); p.out = dT[q]; p.mslope = 1.f;
+                    S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
+                }
+            } else {
+                Tensor GH = alloc_t(lo);
+                for (int q = 0; q < P; ++q) { // d(H1) masked by lrelu'(0.2)
+                    EdgeExpandParams p; memset(&p, 0, sizeof(p));
+                    p.B = B; p.H = H << lo; p.W = W << lo; p.s = dpre; p.w = last_bwd(q); p.out = GH[q]; p.mask = H1[q]; p.mslope = 0.2f;
+                    S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
+                }
+                const Tensor& hr_in = nup > 0 ? U[nup - 1] : T;
+                wgrad_all(S, lo, planes_of(hr_in, lo), GH, e->hr, 1.f);
+                Tensor G = nup > 0 ? alloc_t(lo) : dT;
+                for (int pl = 0; pl < P; ++pl) { // HRconv input gradient (masked by the upsample LeakyReLU(0.01) when it feeds a pixel-shuffle)
+                    std::vector<const float*> pan;
+                    for (int k = 0; k < P; ++k) pan.push_back(bwdp(e->hr.bwd_off + ((long long)pl * P + k) * PANEL_FLOATS));
+                    OutDesc fin = out_desc(G[pl], lo);
+                    if (nup > 0) { fin.mask = U[nup - 1][pl]; fin.mslope = 0.01f; }
+                    kloop(S, lo, planes_of(GH, lo), pan, fin, false, 0, nullptr);
+                }
+                for (int u = nup - 1; u >= 0; --u) {
+                    const Tensor& xin = u > 0 ? U[u - 1] : T;
+                    for (int q = 0; q < P; ++q) {                 // dW of the shuffle conv: the four sub-pixel views of gradient plane q against every input plane
+                        std::vector<PlaneIn> gs;
+                        for (int sub = 0; sub < 4; ++sub) gs.push_back(shuf_in(G[q], u, sub));
+                        for (int j = 0; j < P; ++j) wgrad_launch(S, u, {std_in(xin[j], u)}, gs, e->up[u], 1.f, j, 0, q);
+                    }
+                    Tensor Gn = u > 0 ? alloc_t(u) : dT;
+                    for (int pl = 0; pl < P; ++pl) {
+                        std::vector<PlaneIn> ins;
+                        std::vector<const float*> pan;
+                        for (int sub = 0; sub < 4; ++sub)
+                            for (int q = 0; q < P; ++q) {
+                                ins.push_back(shuf_in(G[q], u, sub));
+                                pan.push_back(bwdp(e->up[u].bwd_off + ((long long)pl * (4 * P) + (sub * P + q)) * PANEL_FLOATS));
+                            }
+                        OutDesc fin = out_desc(Gn[pl], u);
+                        if (u > 0) { fin.mask = U[u - 1][pl]; fin.mslope = 0.01f; }
+                        kloop(S, u, ins, pan, fin, false, 0, nullptr);
+                    }
+                    G = Gn;
+                }
+            }
+            // trunk_conv
+            wgrad_all(S, 0, planes_of(rin[blocks], 0), dT, e->trunk, 1.f);
+        }
+        Tensor dR = alloc_t(0);
+        for (int pl = 0; pl < P; ++pl) {
+            std::vector<const float*> pan;
+            for (int k = 0; k < P; ++k) pan.push_back(bwdp(e->trunk.bwd_off + ((long long)pl * P + k) * PANEL_FLOATS));
+            kloop(e->bwd_stages[0], 0, planes_of(dT, 0), pan, out_desc(dR[pl], 0), false, 0, nullptr);
+        }
+        Tensor dS[5] = {Tensor(), alloc_t(0), alloc_t(0), alloc_t(0), alloc_t(0)};
+        for (int i = blocks - 1; i >= 0; --i) {
+            std::vector<Launch>& S = e->bwd_stages[blocks - i];
+            Tensor dOut = dR;
+            for (int r = 2; r >= 0; --r) {
+                const RdbActM& a = acts[i * 3 + r];
+                const float gscale = r == 2 ? 0.04f : 0.2f;
+                const ConvW* cw = &e->rdb[(i * 3 + r) * 5];
+                dS[0] = alloc_t(0);
+                const Tensor* xpl[5] = {&a.xin, &a.xs[0], &a.xs[1], &a.xs[2], &a.xs[3]};
+                // as in build(): dS_j = sum_{c>j} conv^T_c[j](G_c) as ONE K-loop over the planes of G_5 = dOut, G_4 .. G_{j+1}
+                const Tensor* Gp[6] = {nullptr, &dS[1], &dS[2], &dS[3], &dS[4], &dOut}; // G_c, c = 1..5
+                for (int c = 4; c >= 0; --c) { // conv index c (0-based) = conv_{c+1}
+                    std::vector<PlaneIn> xs;
+                    for (int t = 0; t <= c; ++t) for (float* pl : *xpl[t]) xs.push_back(std_in(pl, 0));
+                    wgrad_all(S, 0, xs, *Gp[c + 1], cw[c], c == 4 ? gscale : 1.f);
+                    const int j = c;
+                    for (int pl = 0; pl < P; ++pl) {
+                        std::vector<PlaneIn> ins;
+                        std::vector<const float*> pan;
+                        for (int ii = 0; ii < 5 - j; ++ii) {
+                            const int cc = 5 - ii;          // 1-based conv whose gradient planes these are; its input plane index of (tensor j, plane pl) is j P + pl
+                            for (int q = 0; q < P; ++q) {
+                                ins.push_back(std_in((*Gp[cc])[q], 0));
+                                pan.push_back(bwdp(cw[cc - 1].bwd_off + (((long long)j * P + pl) * P + q) * PANEL_FLOATS));
+                            }
+                        }
+                        OutDesc fin = out_desc(dS[j][pl], 0);
+                        if (j == 0) {
+                            fin.e1 = dOut[pl]; fin.s1 = r == 2 ? 0.2f : 1.f;
+                            if (r == 0) { fin.e2 = dR[pl]; fin.s2 = 1.f; if (i == 0) { fin.e3 = dT[pl]; fin.s3 = 1.f; } }
+                        } else { fin.mask = (*xpl[j])[pl]; fin.mslope = 0.2f; }
+                        kloop(S, 0, ins, pan, fin, false, 0, nullptr);
+                    }
+                }
+                if (dOut[0] != dR[0]) release_t(dOut, 0, true);
+                dOut = dS[0];
+            }
+            release_t(dR, 0, true);
+            dR = dOut;
+        }
+        { // last stage: conv_first weight grad and (optionally) dx
+            std::vector<Launch>& S = e->bwd_stages[blocks + 1];
+            const Tensor dFea = dR;
+            for (int q = 0; q < P; ++q) {
+                EdgeWgradParams p; memset(&p, 0, sizeof(p));
+                p.B = B; p.H = H; p.W = W; p.f = dFea[q]; p.nblocks = EDGE_WGRAD_BLOCKS;
+                const long long wo = e->first_w + 288 * q, bo = e->first_b + 32 * q;
+                S.push_back([eng, p, wo, bo](hipStream_t s) mutable {
+                    p.s = eng->b_x; p.partial = eng->edge_partial; return launch_edge_wgrad(p, 0, eng->b_grads + wo, eng->b_grads + bo, s);
+                });
+            }
+            const float* skipg = sr ? nullptr : dpre;
+            float* dxtmp = alloc1(0);
+            // (all launches of the chain are skipped when the caller wants no dx)
+            for (int q = 0; q < P; ++q) {
+                EdgeReduceParams p; memset(&p, 0, sizeof(p));
+                p.B = B; p.H = H; p.W = W; p.f = dFea[q]; p.w = first_bwd(q);
+                const bool first = q == 0, last = q == P - 1;
+                S.push_back([eng, p, first, last, dxtmp, skipg](hipStream_t s) mutable {
+                    if (!eng->b_dx) return hipSuccess;
+                    if (!first) p.addto = dxtmp;
+                    if (last) { p.skip = skipg; p.y = eng->b_dx; } else p.y = dxtmp;
+                    return launch_edge_reduce(p, s);
+                });
+            }
+        }
+    }
 };
 
 static int ensure_plan(xsd_engine* e, int B, int H, int W, bool train)
@@ -651,8 +958,10 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(XSD_ERR_HIP, "no HIP device available");
     xsd_engine* e = new xsd_engine();
     e->cfg = *cfg;
-    if (cfg->num_filters != 32 || cfg->in_channels != 1 || cfg->out_channels != 1) {
-        // not the shipped configuration (res/configs/models.toml: 32 filters, one image channel): the generic-width path
+    const bool plane_path = cfg->in_channels == 1 && cfg->out_channels == 1 && cfg->num_filters % 32 == 0 && cfg->num_filters <= 128;
+    if (!plane_path) {
+        // neither the shipped configuration (res/configs/models.toml: 32 filters, one image channel) nor a wider net of whole 32-channel
+        // planes (64 / 96 / 128 filters: the dense block's own default is 64, rrdb_blocks.py:23): the generic-width path
         e->generic = GenericNet::create(*cfg);
         if (!e->generic) { delete e; return fail(XSD_ERR_NOMEM, "generic-width engine: device allocation failed"); }
         e->nparams = e->generic->nparams;
@@ -671,8 +980,10 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
         else { delete e; return fail(XSD_ERR_ARG, "XSD_MATH=%s: the math modes are fp32, bf16x6 and f16x3", m); }
     }
     const int blocks = cfg->num_res_blocks, nup = cfg->kind == XSD_KIND_SR ? cfg->num_upsample : 0;
+    const int nf = cfg->num_filters;
+    e->planes = nf / 32;
     long long off = 0, pk = 0, sb = 0;
-    take_conv(off, 32, 1, e->first_w, e->first_b);
+    take_conv(off, nf, 1, e->first_w, e->first_b);
     auto mk = [&](int cout, int cin, int shuffle) {
         ConvW c; take_conv(off, cout, cin, c.w_off, c.b_off);
         c.cout = cout; c.cin = cin; c.shuffle = shuffle;
@@ -685,16 +996,16 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
         e->rrdb_begin.push_back(off);
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 5; ++c) {
-                e->rdb.push_back(mk(32, 32 * (c + 1), 0));
+                e->rdb.push_back(mk(nf, nf * (c + 1), 0));
                 // conv5's gradient arrives as 0.2*dOut (x5*0.2 + x) and, for RDB3, 0.2*0.2*dOut (out*0.2 + x): fold it
                 if (c == 4) e->rdb.back().bwd_scale = r == 2 ? 0.04f : 0.2f;
             }
     }
     e->rrdb_begin.push_back(off);
-    e->trunk = mk(32, 32, 0);
-    take_conv(off, 1, 32, e->last_w, e->last_b);
-    for (int u = 0; u < nup; ++u) e->up.push_back(mk(128, 32, 1));
-    if (cfg->kind == XSD_KIND_SR) e->hr = mk(32, 32, 0);
+    e->trunk = mk(nf, nf, 0);
+    take_conv(off, 1, nf, e->last_w, e->last_b);
+    for (int u = 0; u < nup; ++u) e->up.push_back(mk(4 * nf, nf, 1));
+    if (cfg->kind == XSD_KIND_SR) e->hr = mk(nf, nf, 0);
     e->nparams = off;
     e->pk_floats = pk;
 
@@ -714,7 +1025,7 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     CK(hipMemset(e->amax, 0, sizeof(float) * xsd_engine::AMAX_CAP));
     CK(hipMalloc((void**)&e->zero_page, 512));   // [0,256): zeros (padding source); [256,512): trash (stores of lanes outside the image)
     CK(hipMemset(e->zero_page, 0, 512));
-    CK(hipMalloc((void**)&e->pk_edge, sizeof(float) * 4 * 288));
+    CK(hipMalloc((void**)&e->pk_edge, sizeof(float) * 4 * 288 * e->planes));   // [first_fwd | first_bwd | last_fwd | last_bwd][plane][288]
     CK(hipMalloc((void**)&e->pk_sbias, sizeof(float) * (sb ? sb : 1)));
     CK(hipMalloc((void**)&e->descs_dev, sizeof(PackDesc) * descs.size()));
     CK(hipMemcpy(e->descs_dev, descs.data(), sizeof(PackDesc) * descs.size(), hipMemcpyHostToDevice));
@@ -770,9 +1081,10 @@ int xsd_pack_weights(xsd_engine* e, const float* dev_params, void* stream)
     }
     else
         HIPCHK(launch_pack_weights(dev_params, e->descs_dev, e->ndesc, e->pk_fwd, e->pk_bwd, s));
-    HIPCHK(launch_pack_edge(dev_params + e->first_w, dev_params + e->last_w, e->pk_edge, e->pk_edge + 288, e->pk_edge + 576,
-                            e->pk_edge + 864, s));
-    for (auto& c : e->up) HIPCHK(launch_pack_shuffle_bias(dev_params + c.b_off, e->pk_sbias + c.sbias_off, s));
+    for (int q = 0, P = e->planes; q < P; ++q)      // conv_first W[c][0][tap] and conv_last W[0][c][tap], 32 channels (one plane) at a time
+        HIPCHK(launch_pack_edge(dev_params + e->first_w + 288 * q, dev_params + e->last_w + 288 * q, e->pk_edge + 288 * q, e->pk_edge + 288 * (P + q),
+                                e->pk_edge + 288 * (2 * P + q), e->pk_edge + 288 * (3 * P + q), s));
+    for (auto& c : e->up) HIPCHK(launch_pack_shuffle_bias(dev_params + c.b_off, e->pk_sbias + c.sbias_off, e->planes, s));
     e->packed = true;
     return XSD_OK;
 }

@@ -132,7 +132,9 @@ struct WgradReduceParams {
     const float* bias_partial;
     int nparts, n_in, n_g;
     int cin_total, cout_total;
-    int shuffle;   // 1: output channel oc = 4*co + n (pixel-shuffle conv), else oc = 32*n + co
+    int shuffle;   // 1: output channel oc = 4*(32*plane + co) + n (pixel-shuffle conv, n = sub-pixel), else oc = 32*(n0 + n) + co
+    int j0, n0;    // first input plane / first output chunk of this launch inside the conv (wide nets launch a conv's blocks in groups)
+    int plane;     // shuffle: which 32-channel plane of the high-resolution tensor the four sub-pixel gradients belong to
     float scale;
     float* dw;     // OIHW [cout_total][cin_total][3][3]
     float* db;     // [cout_total]
