@@ -286,7 +286,7 @@ def test_full_size_properties():
     assert float((ys["f16x3"] - ys["fp32"]).abs().max()) < 5e-6
 
 
-@pytest.mark.parametrize("kind", ["dn", "sr", "dn_16_filters_2_channels"])
+@pytest.mark.parametrize("kind", ["dn", "sr", "dn_16_filters_2_channels", "dn_64_filters"])
 def test_memory_efficient_recompute_matches_full_batch(kind, monkeypatch):
     """memory_efficient=True (rrdb_blocks.py:39-47: same math, activations recomputed in backward) keeps no activations
     between forward and backward and recomputes XSD_ME_CHUNK tiles at a time.  Outputs are bitwise those of the plain
@@ -298,6 +298,7 @@ def test_memory_efficient_recompute_matches_full_batch(kind, monkeypatch):
     ch = 2 if kind == "dn_16_filters_2_channels" else 1        # (the generic-width engine, csrc/generic_net.hip)
     mk = (lambda me: GeneratorRRDB_DN(1, 1, 32, 1, memory_efficient=me)) if kind == "dn" else \
          (lambda me: GeneratorRRDB_SR(1, 1, 32, 1, num_upsample=1, memory_efficient=me)) if kind == "sr" else \
+         (lambda me: GeneratorRRDB_DN(1, 1, 64, 1, memory_efficient=me)) if kind == "dn_64_filters" else \
          (lambda me: GeneratorRRDB_DN(2, 2, 16, 1, memory_efficient=me))
     plain, me = mk(False).cuda(), mk(True).cuda()
     me.load_state_dict(plain.state_dict())
