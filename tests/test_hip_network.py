@@ -435,11 +435,11 @@ def _widths_vs_float64(kind, nf, in_ch, out_ch, blocks, nup, shape, math=None):
 
 
 @pytest.mark.parametrize("math", MATHS)
-@pytest.mark.parametrize("kind,nf,blocks,nup,shape", [("dn", 64, 1, 1, (2, 24, 40)), ("sr", 128, 1, 1, (1, 12, 33))])
+@pytest.mark.parametrize("kind,nf,blocks,nup,shape", [("dn", 64, 1, 1, (2, 24, 40)), ("sr", 128, 1, 1, (1, 12, 33)), ("dn", 160, 1, 1, (1, 10, 21)), ("sr", 256, 1, 1, (1, 7, 9))])
 def test_wide_plane_nets_in_every_math_mode(kind, nf, blocks, nup, shape, math):
-    """64 / 96 / 128 filters with one image channel run on the 32-filter configuration's own kernels, a feature tensor being
-    2 - 4 planes of 32 channels and a conv's K-loop cut into launches of <= 5 planes that accumulate (csrc/xsd_engine.hip,
+    """64, 96, ... 256 filters with one image channel run on the 32-filter configuration's own kernels, a feature tensor being
+    2 - 8 planes of 32 channels and a conv's K-loop cut into launches of <= 5 planes that accumulate (csrc/xsd_engine.hip,
     Builder::build_multi; the dense block's default width is 64, rrdb_blocks.py:23).  Forward, dL/dx and every parameter
-    gradient against float64 in each math mode (the 128-filter SR case: four planes, a 128 -> 512 shuffle conv, K-loops of up
-    to 20 planes)."""
+    gradient against float64 in each math mode (the 256-filter SR case: eight planes, a 256 -> 1024 shuffle conv, K-loops of
+    up to 40 planes)."""
     _widths_vs_float64(kind, nf, 1, 1, blocks, nup, shape, math=math)

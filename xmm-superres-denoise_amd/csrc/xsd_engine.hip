@@ -69,8 +69,8 @@ struct ProfRec { hipEvent_t a, b; double flop, bytes; int klass; };
 
 struct xsd_engine {
     xsd_config cfg;
-    GenericNet* generic = nullptr;   // widths the plane kernels do not take (generic_net.hip): filters that are no multiple of 32 or > 128, image channels != 1
-    int planes = 1;                  // num_filters / 32: 32-channel planes per feature tensor (1 = the shipped configuration; 2..4: Builder::build_multi)
+    GenericNet* generic = nullptr;   // widths the plane kernels do not take (generic_net.hip): filters that are no multiple of 32 or > 256, image channels != 1
+    int planes = 1;                  // num_filters / 32: 32-channel planes per feature tensor (1 = the shipped configuration; 2..8: Builder::build_multi)
     long long nparams = 0;
     // flat-param offsets
     long long first_w = 0, first_b = 0, last_w = 0, last_b = 0;
@@ -605,7 +605,7 @@ struct Builder {
     }
 
     // ---------------------------------------------------------------------------------------------------------
-    // Wide nets: num_filters = 32 P (P = 2..4), one image channel -- the dense block's own default width is 64
+    // Wide nets: num_filters = 32 P (P = 2..8), one image channel -- the dense block's own default width is 64
     // (rrdb_blocks.py:23).  A feature tensor is P planes of 32 channels in torch.cat's channel order; a conv with 32 a
     // inputs and 32 b outputs is b output chunks, each ONE K-loop over the a input planes, cut into launches of <= 5 planes: the
     // first launch carries the bias, the later ones add to the plane it wrote (`accumulate` epilogue), the last one carries the
@@ -958,10 +958,10 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(XSD_ERR_HIP, "no HIP device available");
     xsd_engine* e = new xsd_engine();
     e->cfg = *cfg;
-    const bool plane_path = cfg->in_channels == 1 && cfg->out_channels == 1 && cfg->num_filters % 32 == 0 && cfg->num_filters <= 128;
+    const bool plane_path = cfg->in_channels == 1 && cfg->out_channels == 1 && cfg->num_filters % 32 == 0 && cfg->num_filters <= 256;
     if (!plane_path) {
         // neither the shipped configuration (res/configs/models.toml: 32 filters, one image channel) nor a wider net of whole 32-channel
-        // planes (64 / 96 / 128 filters: the dense block's own default is 64, rrdb_blocks.py:23): the generic-width path
+        // planes (64, 96, ... 256 filters: the dense block's own default is 64, rrdb_blocks.py:23): the generic-width path
         e->generic = GenericNet::create(*cfg);
         if (!e->generic) { delete e; return fail(XSD_ERR_NOMEM, "generic-width engine: device allocation failed"); }
         e->nparams = e->generic->nparams;
