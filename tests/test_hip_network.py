@@ -385,6 +385,9 @@ def test_backward_rejects_mismatched_dy_and_stale_generation():
     ("sr", 64, 1, 1, 1, 1, (2, 19, 37)),     # 64 filters, one image channel: the plane kernels with two planes per tensor (Builder::build_multi), shuffle conv 64 -> 256
     ("sr", 64, 1, 1, 2, 2, (1, 9, 11)),      # ... two pixel-shuffle stages, two blocks
     ("dn", 96, 1, 1, 1, 1, (1, 17, 40)),     # three planes per tensor: K-loops of up to 15 planes in launches of five
+    ("sr", 32, 3, 2, 1, 1, (2, 18, 35)),     # the shipped width with RGB in / two channels out: plane kernels, image-side layers per image channel
+    ("dn", 32, 2, 2, 2, 1, (1, 33, 20)),     # ... DN with its skip per channel
+    ("dn", 64, 4, 4, 1, 1, (1, 12, 34)),
 ])
 def test_generic_widths_vs_float64_restatement(kind, nf, in_ch, out_ch, blocks, nup, shape):
     """Widths other than the shipped 32 / 1 / 1 (reference constructors take any: generator_rrdb.py:10-54) run on the

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams
     const int nrows = P.B * P.H;
     for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int y = row % P.H;
-        const float* sb = P.s + (long long)(row - y) * P.W;
+        const float* sb = P.s + (P.s_bs ? (long long)(row / P.H) * P.s_bs : (long long)(row - y) * P.W);
         __syncthreads();
         for (int i = threadIdx.x; i < 3 * (P.W + 2); i += 256) {
             const int k = i / (P.W + 2), xx = i - k * (P.W + 2) - 1, yy = y + k - 1;
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams
         const long long rbase = (long long)row * P.W * 32;
         for (int x = px0; x < P.W; x += 32) {
             f32x4 v = b4;
+            if (P.accumulate) v += *reinterpret_cast<const f32x4*>(P.out + rbase + (long long)x * 32 + q * 4);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) v += srow[tap / 3][x + tap % 3] * w4[tap];
             const long long o = rbase + (long long)x * 32;
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeReduceParams
         const int sx = blk % stripsX, by = (blk / stripsX) % bandsY, b = blk / (stripsX * bandsY);
         const int x = sx * 32 + px, y0 = by * EDGE_BAND;
         const float* fb = P.f + (long long)b * P.H * P.W * 32;
-        const long long ob = (long long)b * P.H * P.W;
+        const long long ob = P.y_bs ? (long long)b * P.y_bs : (long long)b * P.H * P.W;
+        const long long sob = P.skip_bs ? (long long)b * P.skip_bs : (long long)b * P.H * P.W;
         auto load = [&](int yy, int xx) { // branch-free: out-of-image taps read the image's first pixel and are zeroed
             const bool ok = yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
             const float* pxp = fb + (ok ? ((long long)yy * P.W + xx) * 32 : 0);
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeReduceParams
             // the scalar side inputs of this output pixel travel with the feature loads (one memory latency per row, not two)
             const bool owner = q == 0 && x < P.W;
             const long long pix = ob + (long long)y * P.W + x;
-            const float sk = (owner && P.skip) ? P.skip[pix] : 0.f;
+            const float sk = (owner && P.skip) ? P.skip[sob + (long long)y * P.W + x] : 0.f;
             const float ad = (owner && P.addto) ? P.addto[pix] : 0.f;
             f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const EdgeWgradParams P
     const int nrows = P.B * P.H;
     for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int y = row % P.H;
-        const float* sb = P.s + (long long)(row - y) * P.W;     // image base
+        const float* sb = P.s + (P.s_bs ? (long long)(row / P.H) * P.s_bs : (long long)(row - y) * P.W);     // image base
         __syncthreads();
         for (int i = threadIdx.x; i < 3 * (P.W + 2); i += 256) {
             const int k = i / (P.W + 2), xx = i - k * (P.W + 2) - 1, yy = y + k - 1;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const EdgeWgradParams P
     }
 }
 
-__global__ void edge_wgrad_final_kernel(const float* partial, int nblocks, int mode, float* dw, float* db)
+__global__ void edge_wgrad_final_kernel(const float* partial, int nblocks, int mode, float* dw, float* db, int cstride)
 {
     // one 64-lane wave per output element: lane l sums blocks l, l+64, ... then a fixed-order shuffle tree
     const int e = blockIdx.x;
@@ -199,7 +201,7 @@ __global__ void edge_wgrad_final_kernel(const float* partial, int nblocks, int m
     for (int k = 32; k > 0; k >>= 1) s += __shfl_down(s, k);
     if (threadIdx.x != 0) return;
     if (mode == 0) { // conv_first: dW[c][0][tap], db[c]
-        if (e < 288) dw[(e & 31) * 9 + (e >> 5)] = (float)s;
+        if (e < 288) dw[(e & 31) * cstride + (e >> 5)] = (float)s;      // cstride = 9 * in_channels: W[c][ch][tap], ch folded into dw
         else if (e < 320) db[e - 288] = (float)s;
     } else {         // conv_last: dW[0][c][8-tap], db[0] = ssum
         if (e < 288) dw[(e & 31) * 9 + (8 - (e >> 5))] = (float)s;
@@ -384,15 +386,21 @@ __global__ void split_panels_f16_kernel(const float* src, unsigned int* dst, lon
 // edge-layer weights: conv_first W[c][0][tap] -> [tap][c] (forward) ; conv_last W[0][c][tap] -> [tap][c] (forward)
 // and the flipped forms used by their input-gradients.
 __global__ void pack_edge_kernel(const float* w_first, const float* w_last, float* first_fwd, float* first_bwd,
-                                 float* last_fwd, float* last_bwd)
+                                 float* last_fwd, float* last_bwd, int first_cstride)
 {
+    // first_cstride: floats between consecutive output channels of conv_first = 9 * in_channels (w_first points at the
+    // input channel being packed); either side may be null (in_channels and out_channels differ)
     const int e = threadIdx.x + blockIdx.x * blockDim.x;
     if (e >= 288) return;
     const int tap = e >> 5, c = e & 31;
-    first_fwd[e] = w_first[c * 9 + tap];       // out[p][c] += x[p+tap] * W[c][0][tap]
-    first_bwd[e] = w_first[c * 9 + (8 - tap)]; // dx[p] += sum_c g[p+tap'][c] * W[c][0][8-tap']
-    last_fwd[e] = w_last[c * 9 + tap];         // y[p] += f[p+tap][c] * W[0][c][tap]
-    last_bwd[e] = w_last[c * 9 + (8 - tap)];   // dT[p][c] += dy[p+tap'] * W[0][c][8-tap']
+    if (w_first) {
+        first_fwd[e] = w_first[c * first_cstride + tap];       // out[p][c] += x[p+tap] * W[c][ch][tap]
+        first_bwd[e] = w_first[c * first_cstride + (8 - tap)]; // dx[p] += sum_c g[p+tap'][c] * W[c][ch][8-tap']
+    }
+    if (w_last) {
+        last_fwd[e] = w_last[c * 9 + tap];         // y[p] += f[p+tap][c] * W[co][c][tap]
+        last_bwd[e] = w_last[c * 9 + (8 - tap)];   // dT[p][c] += dy[p+tap'] * W[co][c][8-tap']
+    }
 }
 
 // bias of the pixel-shuffle conv (4 * 32 P outputs) in chunk order: chunk n = sub-pixel * P + plane q holds the channels
@@ -545,10 +553,10 @@ hipError_t launch_edge_reduce(const EdgeReduceParams& p, hipStream_t s)
     hipLaunchKernelGGL(edge_reduce_kernel, dim3((unsigned)(nblk < 8192 ? nblk : 8192)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
-hipError_t launch_edge_wgrad(const EdgeWgradParams& p, int mode, float* dw, float* db, hipStream_t s)
+hipError_t launch_edge_wgrad(const EdgeWgradParams& p, int mode, float* dw, float* db, hipStream_t s, int cstride)
 {
     hipLaunchKernelGGL(edge_wgrad_kernel, dim3(p.nblocks), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(edge_wgrad_final_kernel, dim3(321), dim3(64), 0, s, p.partial, p.nblocks, mode, dw, db);
+    hipLaunchKernelGGL(edge_wgrad_final_kernel, dim3(321), dim3(64), 0, s, p.partial, p.nblocks, mode, dw, db, cstride);
     return hipGetLastError();
 }
 hipError_t launch_clamp_bwd(const float* pre, const float* dy, float* dpre, long long n, hipStream_t s)
@@ -600,9 +608,9 @@ hipError_t launch_split_panels_f16(const float* src, void* dst, long long nfloat
     return hipGetLastError();
 }
 hipError_t launch_pack_edge(const float* w_first, const float* w_last, float* ff, float* fb, float* lf, float* lb,
-                            hipStream_t s)
+                            hipStream_t s, int first_cstride)
 {
-    hipLaunchKernelGGL(pack_edge_kernel, dim3(2), dim3(256), 0, s, w_first, w_last, ff, fb, lf, lb);
+    hipLaunchKernelGGL(pack_edge_kernel, dim3(2), dim3(256), 0, s, w_first, w_last, ff, fb, lf, lb, first_cstride);
     return hipGetLastError();
 }
 hipError_t launch_pack_shuffle_bias(const float* b, float* out, int planes, hipStream_t s)

@@ -26,7 +26,7 @@ hipError_t launch_wgrad_mfma(const WgradParams& p, hipStream_t stream);
 hipError_t launch_wgrad_reduce(const WgradReduceParams& r, hipStream_t stream);
 hipError_t launch_edge_expand(const EdgeExpandParams& p, hipStream_t s);
 hipError_t launch_edge_reduce(const EdgeReduceParams& p, hipStream_t s);
-hipError_t launch_edge_wgrad(const EdgeWgradParams& p, int mode, float* dw, float* db, hipStream_t s);
+hipError_t launch_edge_wgrad(const EdgeWgradParams& p, int mode, float* dw, float* db, hipStream_t s, int cstride = 9);
 hipError_t launch_clamp_bwd(const float* pre, const float* dy, float* dpre, long long n, hipStream_t s);
 hipError_t launch_l1_loss(const float* y, const float* t, float* dy, double* partial, int nblocks, float* loss,
                           long long n, hipStream_t s);
@@ -44,7 +44,7 @@ hipError_t launch_buffer_amax(const float* v, long long n, float* slot, hipStrea
 hipError_t launch_split_panels_f16(const float* src, void* dst, long long nfloats, const float* amax, hipStream_t s);
 hipError_t launch_conv3x3_h2x(const ConvParams& p, hipStream_t stream);
 hipError_t launch_pack_edge(const float* w_first, const float* w_last, float* ff, float* fb, float* lf, float* lb,
-                            hipStream_t s);
+                            hipStream_t s, int first_cstride = 9);
 hipError_t launch_mask_pad_normalize(const MaskPadParams& p, hipStream_t s);
 hipError_t launch_normalize(const float* in, float* out, long long n, float max_val, int mode, int inverse, hipStream_t s);
 hipError_t launch_upsample_nearest(const float* in, float* out, int N, int H, int W, int sc, hipStream_t s);

@@ -69,7 +69,7 @@ struct ProfRec { hipEvent_t a, b; double flop, bytes; int klass; };
 
 struct xsd_engine {
     xsd_config cfg;
-    GenericNet* generic = nullptr;   // widths the plane kernels do not take (generic_net.hip): filters that are no multiple of 32 or > 256, image channels != 1
+    GenericNet* generic = nullptr;   // widths the plane kernels do not take (generic_net.hip): filters that are no multiple of 32 or > 256, more than 8 image channels, a DN skip that broadcasts
     int planes = 1;                  // num_filters / 32: 32-channel planes per feature tensor (1 = the shipped configuration; 2..8: Builder::build_multi)
     long long nparams = 0;
     // flat-param offsets
@@ -232,6 +232,11 @@ struct Builder {
         size_t off = top; top += plane_bytes(level, 1); if (top > peak) peak = top;
         return reinterpret_cast<float*>(base + off);
     }
+    float* alloc_img(int level, int ch) // ch-channel image [B][ch][H][W]
+    {
+        size_t off = top; top += plane_bytes(level, ch); if (top > peak) peak = top;
+        return reinterpret_cast<float*>(base + off);
+    }
     void release(float* p, int level, bool force = false)
     {
         if (train && !force) return; // saved for backward
@@ -370,7 +375,7 @@ struct Builder {
     // ---------------------------------------------------------------------------------------------------------
     void build()
     {
-        if (e->planes > 1) { build_multi(); return; }
+        if (e->planes > 1 || e->cfg.in_channels != 1 || e->cfg.out_channels != 1) { build_multi(); return; }
         xsd_engine* eng = e;
         const int blocks = e->cfg.num_res_blocks;
         const bool sr = e->cfg.kind == XSD_KIND_SR;
@@ -605,7 +610,7 @@ struct Builder {
     }
 
     // ---------------------------------------------------------------------------------------------------------
-    // Wide nets: num_filters = 32 P (P = 2..8), one image channel -- the dense block's own default width is 64
+    // Wide nets and image channels: num_filters = 32 P (P = 1..8), 1..8 image channels -- the dense block's own default width is 64
     // (rrdb_blocks.py:23).  A feature tensor is P planes of 32 channels in torch.cat's channel order; a conv with 32 a
     // inputs and 32 b outputs is b output chunks, each ONE K-loop over the a input planes, cut into launches of <= 5 planes: the
     // first launch carries the bias, the later ones add to the plane it wrote (`accumulate` epilogue), the last one carries the
@@ -623,11 +628,13 @@ struct Builder {
         std::vector<Launch>& F = e->fwd_ops;
         F.clear();
         e->bwd_stages.assign(blocks + 2, {});
-        const float* edge = e->pk_edge;      // [first_fwd | first_bwd | last_fwd | last_bwd][plane][288]
-        auto first_fwd = [&](int q) { return edge + 288 * q; };
-        auto first_bwd = [&](int q) { return edge + 288 * (P + q); };
-        auto last_fwd = [&](int q) { return edge + 288 * (2 * P + q); };
-        auto last_bwd = [&](int q) { return edge + 288 * (3 * P + q); };
+        const int CI = e->cfg.in_channels, CO = e->cfg.out_channels;    // image channels: the image-side layers run one (image channel, plane) at a time
+        const float* edge = e->pk_edge;      // [first_fwd | first_bwd][in channel][plane][288], [last_fwd | last_bwd][out channel][plane][288]
+        auto first_fwd = [&](int ch, int q) { return edge + 288 * (ch * P + q); };
+        auto first_bwd = [&](int ch, int q) { return edge + 288 * (P * CI + ch * P + q); };
+        auto last_fwd = [&](int co, int q) { return edge + 288 * (2 * P * CI + co * P + q); };
+        auto last_bwd = [&](int co, int q) { return edge + 288 * (2 * P * CI + P * CO + co * P + q); };
+        const long long HW = (long long)H * W;
 
         auto alloc_t = [&](int level) { Tensor t(P); for (auto& p : t) p = alloc(level); return t; };
         auto release_t = [&](const Tensor& t, int level, bool force = false) { for (float* p : t) release(p, level, force); };
@@ -660,35 +667,20 @@ struct Builder {
                     wgrad_launch(ops, level, grp, {std_in(g[q], level)}, cw, scale, base, q, 0);
                 }
         };
-        // 32P -> 1 edge conv over the planes of `f`: partial sums chained through `tmp`; `fin` fills in the last launch
-        auto reduce_chain = [&](std::vector<Launch>& ops, const Tensor& f, int level, const std::function<const float*(int)>& w, long long bias_off,
-                                float* tmp, const std::function<bool(EdgeReduceParams&)>& fin) {
-            for (int q = 0; q < P; ++q) {
-                EdgeReduceParams p; memset(&p, 0, sizeof(p));
-                p.B = B; p.H = H << level; p.W = W << level; p.f = f[q]; p.w = w(q);
-                const bool first = q == 0, last = q == P - 1;
-                ops.push_back([eng, p, first, last, bias_off, tmp, fin](hipStream_t s) mutable {
-                    if (first && bias_off >= 0) p.bias = eng->params + bias_off;
-                    if (!first) p.addto = tmp;
-                    if (last) { if (!fin(p)) return hipSuccess; }
-                    else p.y = tmp;
-                    return launch_edge_reduce(p, s);
-                });
-            }
-        };
-
         struct RdbActM { Tensor xin, xs[4], out; };
         std::vector<RdbActM> acts(blocks * 3);
         std::vector<Tensor> rin(blocks + 1);
 
         // ---- forward ------------------------------------------------------------------------------------------
         Tensor fea = alloc_t(0);
-        for (int q = 0; q < P; ++q) { // conv_first (generator_rrdb.py:67), 32 output channels per launch
-            EdgeExpandParams p; memset(&p, 0, sizeof(p));
-            p.B = B; p.H = H; p.W = W; p.out = fea[q]; p.w = first_fwd(q); p.mslope = 1.f;
-            const long long boff = e->first_b + 32 * q;
-            F.push_back([eng, p, boff](hipStream_t s) mutable { p.s = eng->b_x; p.bias = eng->params + boff; return launch_edge_expand(p, s); });
-        }
+        for (int q = 0; q < P; ++q)   // conv_first (generator_rrdb.py:67), 32 output channels of one image channel per launch
+            for (int ch = 0; ch < CI; ++ch) {
+                EdgeExpandParams p; memset(&p, 0, sizeof(p));
+                p.B = B; p.H = H; p.W = W; p.out = fea[q]; p.w = first_fwd(ch, q); p.mslope = 1.f; p.s_bs = CI * HW; p.accumulate = ch > 0;
+                const long long boff = e->first_b + 32 * q, xo = ch * HW;
+                F.push_back([eng, p, boff, xo, ch](hipStream_t s) mutable {
+                    p.s = eng->b_x + xo; p.bias = ch == 0 ? eng->params + boff : nullptr; return launch_edge_expand(p, s); });
+            }
         Tensor cur = fea;
         for (int i = 0; i < blocks; ++i) {
             rin[i] = cur;
@@ -762,42 +754,60 @@ struct Builder {
             }
             release_t(feat, lo);
         }
-        float* pre = train ? alloc1(lo) : nullptr;
-        float* ytmp = alloc1(lo);
+        const long long HWo = (long long)(H << lo) * (W << lo);
+        float* pre = train ? alloc_img(lo, CO) : nullptr;
         const Tensor& headf = sr ? H1 : T;
-        // conv_last (+x for DN) + clamp, clamp (generator_rrdb.py:107-108,132-135; model.py:49)
-        reduce_chain(F, headf, lo, last_fwd, e->last_b, ytmp, [eng, pre, sr](EdgeReduceParams& p) {
-            p.skip = sr ? nullptr : eng->b_x; p.pre = pre; p.clamp01 = 1; p.y = eng->b_y; return true; });
+        // conv_last (+x for DN) + clamp, clamp (generator_rrdb.py:107-108,132-135; model.py:49): per output channel the planes' partial
+        // sums chained in place through y, the last launch adds the skip and clamps
+        for (int co = 0; co < CO; ++co)
+            for (int q = 0; q < P; ++q) {
+                EdgeReduceParams p; memset(&p, 0, sizeof(p));
+                p.B = B; p.H = H << lo; p.W = W << lo; p.f = headf[q]; p.w = last_fwd(co, q); p.y_bs = CO * HWo; p.skip_bs = CI * HW;
+                const bool first = q == 0, last = q == P - 1;
+                const long long boff = e->last_b + co, yo = co * HWo, xo = co * HW;
+                F.push_back([eng, p, first, last, boff, yo, xo, pre, sr](hipStream_t s) mutable {
+                    p.y = eng->b_y + yo;
+                    if (first) p.bias = eng->params + boff; else p.addto = p.y;
+                    if (last) { p.skip = sr ? nullptr : eng->b_x + xo; p.pre = pre ? pre + yo : nullptr; p.clamp01 = 1; }
+                    return launch_edge_reduce(p, s);
+                });
+            }
         if (!train) return;
 
         // ---- backward -----------------------------------------------------------------------------------------
-        float* dpre = alloc1(lo);
+        float* dpre = alloc_img(lo, CO);
         Tensor dT = alloc_t(0);
         { // stage 0: output head
             std::vector<Launch>& S = e->bwd_stages[0];
-            const long long npx = (long long)B * (H << lo) * (W << lo);
+            const long long npx = (long long)B * CO * HWo;
             S.push_back([eng, pre, dpre, npx](hipStream_t s) { return launch_clamp_bwd(pre, eng->b_dy, dpre, npx, s); });
-            for (int q = 0; q < P; ++q) { // conv_last weight grad, 32 input channels per launch (the bias gradient is the same sum every time)
+            for (int co = 0; co < CO; ++co)
+            for (int q = 0; q < P; ++q) { // conv_last weight grad, 32 input channels of one output channel per launch (the bias gradient is the same sum every time)
                 EdgeWgradParams p; memset(&p, 0, sizeof(p));
-                p.B = B; p.H = H << lo; p.W = W << lo; p.f = headf[q]; p.s = dpre; p.nblocks = EDGE_WGRAD_BLOCKS;
-                const long long wo = e->last_w + 288 * q, bo = e->last_b;
+                p.B = B; p.H = H << lo; p.W = W << lo; p.f = headf[q]; p.s = dpre + co * HWo; p.s_bs = CO * HWo; p.nblocks = EDGE_WGRAD_BLOCKS;
+                const long long wo = e->last_w + ((long long)co * 32 * P + 32 * q) * 9, bo = e->last_b + co;
                 S.push_back([eng, p, wo, bo](hipStream_t s) mutable {
                     p.partial = eng->edge_partial; return launch_edge_wgrad(p, 1, eng->b_grads + wo, eng->b_grads + bo, s);
                 });
             }
             if (!sr) {
-                for (int q = 0; q < P; ++q) {
-                    EdgeExpandParams p; memset(&p, 0, sizeof(p));
-                    p.B = B; p.H = H; p.W = W; p.s = dpre; p.w = last_bwd(q); p.out = dT[q]; p.mslope = 1.f;
-                    S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
-                }
+                for (int q = 0; q < P; ++q)
+                    for (int co = 0; co < CO; ++co) {
+                        EdgeExpandParams p; memset(&p, 0, sizeof(p));
+                        p.B = B; p.H = H; p.W = W; p.s = dpre + co * HWo; p.s_bs = CO * HWo; p.w = last_bwd(co, q); p.out = dT[q]; p.mslope = 1.f;
+                        p.accumulate = co > 0;
+                        S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
+                    }
             } else {
                 Tensor GH = alloc_t(lo);
-                for (int q = 0; q < P; ++q) { // d(H1) masked by lrelu'(0.2)
-                    EdgeExpandParams p; memset(&p, 0, sizeof(p));
-                    p.B = B; p.H = H << lo; p.W = W << lo; p.s = dpre; p.w = last_bwd(q); p.out = GH[q]; p.mask = H1[q]; p.mslope = 0.2f;
-                    S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
-                }
+                for (int q = 0; q < P; ++q)   // d(H1) masked by lrelu'(0.2): the output channels' contributions summed, the mask on the last
+                    for (int co = 0; co < CO; ++co) {
+                        EdgeExpandParams p; memset(&p, 0, sizeof(p));
+                        p.B = B; p.H = H << lo; p.W = W << lo; p.s = dpre + co * HWo; p.s_bs = CO * HWo; p.w = last_bwd(co, q); p.out = GH[q];
+                        p.accumulate = co > 0; p.mslope = 1.f;
+                        if (co == CO - 1) { p.mask = H1[q]; p.mslope = 0.2f; }
+                        S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
+                    }
                 const Tensor& hr_in = nup > 0 ? U[nup - 1] : T;
                 wgrad_all(S, lo, planes_of(hr_in, lo), GH, e->hr, 1.f);
                 Tensor G = nup > 0 ? alloc_t(lo) : dT;
@@ -884,28 +894,33 @@ struct Builder {
         { // last stage: conv_first weight grad and (optionally) dx
             std::vector<Launch>& S = e->bwd_stages[blocks + 1];
             const Tensor dFea = dR;
-            for (int q = 0; q < P; ++q) {
-                EdgeWgradParams p; memset(&p, 0, sizeof(p));
-                p.B = B; p.H = H; p.W = W; p.f = dFea[q]; p.nblocks = EDGE_WGRAD_BLOCKS;
-                const long long wo = e->first_w + 288 * q, bo = e->first_b + 32 * q;
-                S.push_back([eng, p, wo, bo](hipStream_t s) mutable {
-                    p.s = eng->b_x; p.partial = eng->edge_partial; return launch_edge_wgrad(p, 0, eng->b_grads + wo, eng->b_grads + bo, s);
-                });
-            }
-            const float* skipg = sr ? nullptr : dpre;
-            float* dxtmp = alloc1(0);
-            // (all launches of the chain are skipped when the caller wants no dx)
-            for (int q = 0; q < P; ++q) {
-                EdgeReduceParams p; memset(&p, 0, sizeof(p));
-                p.B = B; p.H = H; p.W = W; p.f = dFea[q]; p.w = first_bwd(q);
-                const bool first = q == 0, last = q == P - 1;
-                S.push_back([eng, p, first, last, dxtmp, skipg](hipStream_t s) mutable {
-                    if (!eng->b_dx) return hipSuccess;
-                    if (!first) p.addto = dxtmp;
-                    if (last) { p.skip = skipg; p.y = eng->b_dx; } else p.y = dxtmp;
-                    return launch_edge_reduce(p, s);
-                });
-            }
+            for (int ch = 0; ch < CI; ++ch)
+                for (int q = 0; q < P; ++q) {
+                    EdgeWgradParams p; memset(&p, 0, sizeof(p));
+                    p.B = B; p.H = H; p.W = W; p.f = dFea[q]; p.nblocks = EDGE_WGRAD_BLOCKS; p.s_bs = CI * HW;
+                    const long long wo = e->first_w + ((long long)32 * q * CI + ch) * 9, bo = e->first_b + 32 * q, xo = ch * HW;
+                    const int cstride = 9 * CI;
+                    S.push_back([eng, p, wo, bo, xo, cstride](hipStream_t s) mutable {
+                        p.s = eng->b_x + xo; p.partial = eng->edge_partial;
+                        return launch_edge_wgrad(p, 0, eng->b_grads + wo, eng->b_grads + bo, s, cstride);
+                    });
+                }
+            const float* skipg = sr ? nullptr : dpre;     // DN: d(out + x)/dx (in_channels == out_channels on this path)
+            // dx per image channel: the planes' partial sums chained in place (all launches skipped when the caller wants no dx)
+            for (int ch = 0; ch < CI; ++ch)
+                for (int q = 0; q < P; ++q) {
+                    EdgeReduceParams p; memset(&p, 0, sizeof(p));
+                    p.B = B; p.H = H; p.W = W; p.f = dFea[q]; p.w = first_bwd(ch, q); p.y_bs = CI * HW; p.skip_bs = CO * HW;
+                    const bool first = q == 0, last = q == P - 1;
+                    const long long xo = ch * HW;
+                    S.push_back([eng, p, first, last, xo, skipg](hipStream_t s) mutable {
+                        if (!eng->b_dx) return hipSuccess;
+                        p.y = eng->b_dx + xo;
+                        if (!first) p.addto = p.y;
+                        if (last && skipg) p.skip = skipg + xo;
+                        return launch_edge_reduce(p, s);
+                    });
+                }
         }
     }
 };
@@ -958,7 +973,9 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(XSD_ERR_HIP, "no HIP device available");
     xsd_engine* e = new xsd_engine();
     e->cfg = *cfg;
-    const bool plane_path = cfg->in_channels == 1 && cfg->out_channels == 1 && cfg->num_filters % 32 == 0 && cfg->num_filters <= 256;
+    // whole 32-channel planes, a few image channels; DN's `out + x` with a broadcast x (in_channels 1, out_channels > 1) stays generic
+    const bool plane_path = cfg->num_filters % 32 == 0 && cfg->num_filters <= 256 && cfg->in_channels <= 8 && cfg->out_channels <= 8 &&
+                            (cfg->kind == XSD_KIND_SR || cfg->in_channels == cfg->out_channels);
     if (!plane_path) {
         // neither the shipped configuration (res/configs/models.toml: 32 filters, one image channel) nor a wider net of whole 32-channel
         // planes (64, 96, ... 256 filters: the dense block's own default is 64, rrdb_blocks.py:23): the generic-width path
@@ -983,7 +1000,7 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     const int nf = cfg->num_filters;
     e->planes = nf / 32;
     long long off = 0, pk = 0, sb = 0;
-    take_conv(off, nf, 1, e->first_w, e->first_b);
+    take_conv(off, nf, cfg->in_channels, e->first_w, e->first_b);
     auto mk = [&](int cout, int cin, int shuffle) {
         ConvW c; take_conv(off, cout, cin, c.w_off, c.b_off);
         c.cout = cout; c.cin = cin; c.shuffle = shuffle;
@@ -1003,7 +1020,7 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     }
     e->rrdb_begin.push_back(off);
     e->trunk = mk(nf, nf, 0);
-    take_conv(off, 1, nf, e->last_w, e->last_b);
+    take_conv(off, cfg->out_channels, nf, e->last_w, e->last_b);
     for (int u = 0; u < nup; ++u) e->up.push_back(mk(4 * nf, nf, 1));
     if (cfg->kind == XSD_KIND_SR) e->hr = mk(nf, nf, 0);
     e->nparams = off;
@@ -1025,7 +1042,7 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     CK(hipMemset(e->amax, 0, sizeof(float) * xsd_engine::AMAX_CAP));
     CK(hipMalloc((void**)&e->zero_page, 512));   // [0,256): zeros (padding source); [256,512): trash (stores of lanes outside the image)
     CK(hipMemset(e->zero_page, 0, 512));
-    CK(hipMalloc((void**)&e->pk_edge, sizeof(float) * 4 * 288 * e->planes));   // [first_fwd | first_bwd | last_fwd | last_bwd][plane][288]
+    CK(hipMalloc((void**)&e->pk_edge, sizeof(float) * 2 * 288 * e->planes * (cfg->in_channels + cfg->out_channels)));   // [first_fwd | first_bwd][in channel][plane][288], [last_fwd | last_bwd][out channel][plane][288]
     CK(hipMalloc((void**)&e->pk_sbias, sizeof(float) * (sb ? sb : 1)));
     CK(hipMalloc((void**)&e->descs_dev, sizeof(PackDesc) * descs.size()));
     CK(hipMemcpy(e->descs_dev, descs.data(), sizeof(PackDesc) * descs.size(), hipMemcpyHostToDevice));
@@ -1081,9 +1098,18 @@ int xsd_pack_weights(xsd_engine* e, const float* dev_params, void* stream)
     }
     else
         HIPCHK(launch_pack_weights(dev_params, e->descs_dev, e->ndesc, e->pk_fwd, e->pk_bwd, s));
-    for (int q = 0, P = e->planes; q < P; ++q)      // conv_first W[c][0][tap] and conv_last W[0][c][tap], 32 channels (one plane) at a time
-        HIPCHK(launch_pack_edge(dev_params + e->first_w + 288 * q, dev_params + e->last_w + 288 * q, e->pk_edge + 288 * q, e->pk_edge + 288 * (P + q),
-                                e->pk_edge + 288 * (2 * P + q), e->pk_edge + 288 * (3 * P + q), s));
+    {   // conv_first W[c][ch][tap] and conv_last W[co][c][tap], 32 feature channels (one plane) of one image channel at a time
+        const int P = e->planes, ci = e->cfg.in_channels, co = e->cfg.out_channels, nf = 32 * P;
+        float* ff = e->pk_edge; float* fb = ff + 288 * P * ci; float* lf = fb + 288 * P * ci; float* lb = lf + 288 * P * co;
+        for (int ch = 0; ch < ci; ++ch)
+            for (int q = 0; q < P; ++q)
+                HIPCHK(launch_pack_edge(dev_params + e->first_w + ((long long)32 * q * ci + ch) * 9, nullptr, ff + 288 * (ch * P + q), fb + 288 * (ch * P + q),
+                                        nullptr, nullptr, s, 9 * ci));
+        for (int o = 0; o < co; ++o)
+            for (int q = 0; q < P; ++q)
+                HIPCHK(launch_pack_edge(nullptr, dev_params + e->last_w + ((long long)o * nf + 32 * q) * 9, nullptr, nullptr, lf + 288 * (o * P + q),
+                                        lb + 288 * (o * P + q), s));
+    }
     for (auto& c : e->up) HIPCHK(launch_pack_shuffle_bias(dev_params + c.b_off, e->pk_sbias + c.sbias_off, e->planes, s));
     e->packed = true;
     return XSD_OK;

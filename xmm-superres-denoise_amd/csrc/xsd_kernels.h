@@ -160,6 +160,8 @@ struct EdgeExpandParams { // 1 -> 32 conv:  out[p][c] = bias[c] + sum_tap s[p+ta
     const float* mask;   // plane or null
     float mslope;
     const unsigned short* bits; // compact form of `mask` (OutDesc::bits_out layout) or null
+    long long s_bs;      // floats between consecutive images of `s` (0: H*W; C*H*W when `s` is one channel of a [B][C][H][W] image)
+    int accumulate;      // add to what `out` holds instead of starting from the bias (second and later image channels)
 };
 struct EdgeReduceParams { // 32 -> 1 conv: pre[p] = bias + sum_tap sum_c f[p+tap][c] * w[tap][c] (+ skip[p]); y = clamp(pre)
     int B, H, W;
@@ -171,6 +173,8 @@ struct EdgeReduceParams { // 32 -> 1 conv: pre[p] = bias + sum_tap sum_c f[p+tap
     float* y;            // output
     int clamp01;
     const float* addto;  // y = value + addto[p] (used for dx = dgrad + skip-grad), may be null
+    long long y_bs;      // floats between consecutive images of y / pre / addto (0: H*W; C*H*W for one channel of a [B][C][H][W] image)
+    long long skip_bs;   // the same for `skip`
 };
 constexpr int EDGE_BAND = 32;     // rows per workgroup of the 32 -> 1 edge conv
 constexpr int EDGE_MAX_W = 4096;  // widest image row the edge kernels stage in LDS
@@ -180,6 +184,7 @@ struct EdgeWgradParams { // out[tap][c] = sum_p f[p][c] * s[p+tap]; bsum[c] = su
     const float* s;
     float* partial;      // [nblocks][9*32 + 32 + 1]
     int nblocks;
+    long long s_bs;      // floats between consecutive images of `s` (0: H*W)
 };
 
 } // namespace xsd

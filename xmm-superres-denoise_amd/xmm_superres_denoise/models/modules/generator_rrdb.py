@@ -120,7 +120,7 @@ class _GeneratorRRDB(nn.Module):
                  memory_efficient: bool = False):
         super().__init__()
         # Any widths, like the reference (generator_rrdb.py:10-54).  The shipped configuration (res/configs/models.toml: 32
-        # filters, one image channel) and 64, 96, ... 256 filters run on the split-precision MFMA kernels; every other one on
+        # filters, one image channel), 64, 96, ... 256 filters and up to 8 image channels run on the split-precision MFMA kernels; every other one on
         # the exact-fp32 kernels of csrc/generic_net.hip.  What cannot work is said HERE, not at the first forward.
         for name, v in (("in_channels", in_channels), ("out_channels", out_channels), ("num_filters", num_filters)):
             if not 1 <= int(v) <= 1024:
