@@ -136,14 +136,14 @@ STEP_BYTES = {("dn", True): 117020.0, ("dn", False): 33420.0, ("sr", True): 1242
 STEP_FLOP = {("dn", True): 2.62e12, ("dn", False): 8.749e11, ("sr", True): 2.74e12, ("sr", False): 9.140e11}   # per tile
 
 
-def roofline_block(math, prof, batch, kind, train, world, tiles_per_s):
+def roofline_block(math, prof, batch, kind, train, world, tiles_per_s, shipped_width=True):
     """roofline of the dominant kernel (the conv: forward + input-gradient launches) from the HIP-event records of the timed
     region; `prof` = {0: conv totals, 1: weight-gradient totals} (Engine.profile_read)."""
     k = prof[0]
     sec = k["ms"] * 1e-3
     tf = k["flop"] / sec / 1e12
     gbs = k["bytes"] / sec / 1e9
-    pmc_ok = train and kind == "dn" and world == 1
+    pmc_ok = train and kind == "dn" and world == 1 and shipped_width
     traffic, tfile = pmc_traffic(math, batch, "conv") if pmc_ok else (None, None)
     hb = {"achieved": gbs, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBPS}
     if math == "fp32":   # exact fp32 MFMA: compute-bound by 4-5x (DESIGN.md section 4)
@@ -163,6 +163,8 @@ def roofline_block(math, prof, batch, kind, train, world, tiles_per_s):
         wt, wfile = pmc_traffic(math, batch, "wgrad") if pmc_ok else (None, None)
         roof["wgrad_kernel"] = {"achieved_TFLOPs": w["flop"] / wsec / 1e12, "achieved_GBps": w["bytes"] / wsec / 1e9,
                                 "launches": w["launches"], "avg_launch_ms": w["ms"] / w["launches"], "traffic": wt, "traffic_from": wfile}
+    if not shipped_width:
+        return roof
     # whole-step algorithmic bytes / flops per tile (fp32 counting rule) x tiles/s against the peaks
     step_bytes = STEP_BYTES[(kind, train)] * TILE * TILE
     step_flop = STEP_FLOP[(kind, train)]
@@ -204,6 +206,9 @@ def main():
     ap.add_argument("--loss", default="l1", choices=["l1", "paper"],
                     help="l1 = BASELINE configs[2]; paper = the reference's shipped default 0.5 psnr + 0.5 ms_ssim with the "
                          "'linear' scaling table (res/configs/loss_functions.toml), reported separately (SURVEY 8d config 3)")
+    ap.add_argument("--filters", type=int, default=32,
+                    help="num_filters of the generator (BASELINE: 32 = res/configs/models.toml).  Other widths are NOT the headline: "
+                         "the line then carries no cpu_baseline, no PMC traffic and no whole-step figures (those are defined for 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--extra-math", default="bf16x6", choices=sorted(MATHS) + ["none"],
@@ -255,7 +260,8 @@ def main():
     scale = 2 if kind == "sr" else 1
 
     torch.manual_seed(0)  # same seeded default init on every rank (DP replicas start identical)
-    model = (GeneratorRRDB_DN(1, 1, 32, 4) if kind == "dn" else GeneratorRRDB_SR(1, 1, 32, 4, num_upsample=1)).to(dev)
+    NF = args.filters
+    model = (GeneratorRRDB_DN(1, 1, NF, 4) if kind == "dn" else GeneratorRRDB_SR(1, 1, NF, 4, num_upsample=1)).to(dev)
     # synthetic data: global batch generated from one seed, each rank takes its shard (DistributedSampler analogue)
     gx = torch.Generator().manual_seed(0)
     gt = torch.Generator().manual_seed(1)
@@ -354,7 +360,7 @@ def main():
                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dte / args.steps,
                  "max_abs_output_diff_vs_" + args.math: err, "note": "not the headline: the strict mode, reported for comparison"}
         if profe is not None and profe[0]["launches"] > 0:
-            extra["roofline"] = roofline_block(xm, profe, B, kind, train, world, B * world * args.steps / dte)
+            extra["roofline"] = roofline_block(xm, profe, B, kind, train, world, B * world * args.steps / dte, NF == 32)
         model.set_math(args.math)
 
     if rank == 0:
@@ -369,16 +375,17 @@ def main():
                                     "sr_train": "XMM-SuperRes 2x train step (%s + Adam)" % ("L1" if args.loss == "l1" else "0.5 PSNR + 0.5 MS-SSIM"),
                                     "dn_fwd": "XMM-DeNoise forward", "sr_fwd": "XMM-SuperRes 2x generator forward"}[args.workload],
                        "tile": f"1x{TILE}x{TILE}", "per_gpu_batch": B, "global_batch": B * world,
-                       "layers": "RRDB generator, 32 filters x 4 blocks (res/configs/models.toml)", "math": args.math,
+                       "layers": "RRDB generator, 32 filters x 4 blocks (res/configs/models.toml)" if NF == 32 else f"RRDB generator, {NF} filters x 4 blocks (NOT the BASELINE width)",
+                       "math": args.math,
                        "parallelism": f"dp{world}", "dist_backend": backend if world > 1 else None},
         }
         if replicas_identical is not None:
             out["replicas_identical"] = replicas_identical
         if prof is not None and prof[0]["launches"] > 0:
-            out["roofline"] = roofline_block(args.math, prof, B, kind, train, world, tiles / dt)
+            out["roofline"] = roofline_block(args.math, prof, B, kind, train, world, tiles / dt, NF == 32)
         if extra is not None:
             out["extra"] = extra
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and NF == 32:
             out["cpu_baseline"] = cpu_baseline(kind, train)
         print(json.dumps(out), flush=True)
     if world > 1:
