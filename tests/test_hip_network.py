@@ -388,6 +388,7 @@ def test_backward_rejects_mismatched_dy_and_stale_generation():
     ("sr", 32, 3, 2, 1, 1, (2, 18, 35)),     # the shipped width with RGB in / two channels out: plane kernels, image-side layers per image channel
     ("dn", 32, 2, 2, 2, 1, (1, 33, 20)),     # ... DN with its skip per channel
     ("dn", 64, 4, 4, 1, 1, (1, 12, 34)),
+    ("dn", 32, 1, 3, 1, 1, (2, 17, 33)),     # ... and with a one-channel x broadcast over three output channels (generator_rrdb.py:134)
 ])
 def test_generic_widths_vs_float64_restatement(kind, nf, in_ch, out_ch, blocks, nup, shape):
     """Widths other than the shipped 32 / 1 / 1 (reference constructors take any: generator_rrdb.py:10-54) run on the

@@ -559,6 +559,23 @@ hipError_t launch_edge_wgrad(const EdgeWgradParams& p, int mode, float* dw, floa
     hipLaunchKernelGGL(edge_wgrad_final_kernel, dim3(321), dim3(64), 0, s, p.partial, p.nblocks, mode, dw, db, cstride);
     return hipGetLastError();
 }
+// dst[b][p] += sum over the C channels of src[b][c][p]: the skip gradient of GeneratorRRDB_DN's `out + x` when a one-channel x
+// broadcasts over several output channels (generator_rrdb.py:134)
+__global__ void add_channels_kernel(float* dst, const float* src, int C, long long HW, int B)
+{
+    const long long total = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / HW, p = i - b * HW;
+        float t = 0.f;
+        for (int c = 0; c < C; ++c) t += src[(b * C + c) * HW + p];
+        dst[i] += t;
+    }
+}
+hipError_t launch_add_channels(float* dst, const float* src, int C, long long HW, int B, hipStream_t s)
+{
+    hipLaunchKernelGGL(add_channels_kernel, dim3(grid_for((long long)B * HW, 256)), dim3(256), 0, s, dst, src, C, HW, B);
+    return hipGetLastError();
+}
 hipError_t launch_clamp_bwd(const float* pre, const float* dy, float* dpre, long long n, hipStream_t s)
 {
     hipLaunchKernelGGL(clamp_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, pre, dy, dpre, n);

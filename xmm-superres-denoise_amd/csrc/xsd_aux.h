@@ -26,6 +26,7 @@ hipError_t launch_wgrad_mfma(const WgradParams& p, hipStream_t stream);
 hipError_t launch_wgrad_reduce(const WgradReduceParams& r, hipStream_t stream);
 hipError_t launch_edge_expand(const EdgeExpandParams& p, hipStream_t s);
 hipError_t launch_edge_reduce(const EdgeReduceParams& p, hipStream_t s);
+hipError_t launch_add_channels(float* dst, const float* src, int C, long long HW, int B, hipStream_t s);
 hipError_t launch_edge_wgrad(const EdgeWgradParams& p, int mode, float* dw, float* db, hipStream_t s, int cstride = 9);
 hipError_t launch_clamp_bwd(const float* pre, const float* dy, float* dpre, long long n, hipStream_t s);
 hipError_t launch_l1_loss(const float* y, const float* t, float* dy, double* partial, int nblocks, float* loss,

@@ -69,7 +69,7 @@ struct ProfRec { hipEvent_t a, b; double flop, bytes; int klass; };
 
 struct xsd_engine {
     xsd_config cfg;
-    GenericNet* generic = nullptr;   // widths the plane kernels do not take (generic_net.hip): filters that are no multiple of 32 or > 256, more than 8 image channels, a DN skip that broadcasts
+    GenericNet* generic = nullptr;   // widths the plane kernels do not take (generic_net.hip): filters that are no multiple of 32 or > 256, more than 8 image channels
     int planes = 1;                  // num_filters / 32: 32-channel planes per feature tensor (1 = the shipped configuration; 2..8: Builder::build_multi)
     long long nparams = 0;
     // flat-param offsets
@@ -764,7 +764,7 @@ struct Builder {
                 EdgeReduceParams p; memset(&p, 0, sizeof(p));
                 p.B = B; p.H = H << lo; p.W = W << lo; p.f = headf[q]; p.w = last_fwd(co, q); p.y_bs = CO * HWo; p.skip_bs = CI * HW;
                 const bool first = q == 0, last = q == P - 1;
-                const long long boff = e->last_b + co, yo = co * HWo, xo = co * HW;
+                const long long boff = e->last_b + co, yo = co * HWo, xo = (CI == 1 ? 0 : co) * HW;   // DN: x broadcasts when it has one channel
                 F.push_back([eng, p, first, last, boff, yo, xo, pre, sr](hipStream_t s) mutable {
                     p.y = eng->b_y + yo;
                     if (first) p.bias = eng->params + boff; else p.addto = p.y;
@@ -905,7 +905,8 @@ struct Builder {
                         return launch_edge_wgrad(p, 0, eng->b_grads + wo, eng->b_grads + bo, s, cstride);
                     });
                 }
-            const float* skipg = sr ? nullptr : dpre;     // DN: d(out + x)/dx (in_channels == out_channels on this path)
+            const bool bcast = !sr && CI == 1 && CO > 1;  // DN with a one-channel x added to every output channel: dx += sum over the channels of dpre
+            const float* skipg = (sr || bcast) ? nullptr : dpre;     // DN: d(out + x)/dx per channel
             // dx per image channel: the planes' partial sums chained in place (all launches skipped when the caller wants no dx)
             for (int ch = 0; ch < CI; ++ch)
                 for (int q = 0; q < P; ++q) {
@@ -921,6 +922,10 @@ struct Builder {
                         return launch_edge_reduce(p, s);
                     });
                 }
+            if (bcast) {
+                const int nb = B, nc = CO;
+                S.push_back([eng, dpre, nb, nc, HW](hipStream_t s) { return eng->b_dx ? launch_add_channels(eng->b_dx, dpre, nc, HW, nb, s) : hipSuccess; });
+            }
         }
     }
 };
@@ -973,9 +978,9 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(XSD_ERR_HIP, "no HIP device available");
     xsd_engine* e = new xsd_engine();
     e->cfg = *cfg;
-    // whole 32-channel planes, a few image channels; DN's `out + x` with a broadcast x (in_channels 1, out_channels > 1) stays generic
+    // whole 32-channel planes, a few image channels
     const bool plane_path = cfg->num_filters % 32 == 0 && cfg->num_filters <= 256 && cfg->in_channels <= 8 && cfg->out_channels <= 8 &&
-                            (cfg->kind == XSD_KIND_SR || cfg->in_channels == cfg->out_channels);
+                            (cfg->kind == XSD_KIND_SR || cfg->in_channels == cfg->out_channels || cfg->in_channels == 1);
     if (!plane_path) {
         // neither the shipped configuration (res/configs/models.toml: 32 filters, one image channel) nor a wider net of whole 32-channel
         // planes (64, 96, ... 256 filters: the dense block's own default is 64, rrdb_blocks.py:23): the generic-width path
