@@ -41,9 +41,10 @@ typedef struct xsd_config {
     int32_t kind;          /* xsd_kind */
     int32_t in_channels;   /* 1..1024 (models.toml: 1).  DN: must equal out_channels or be 1 (`out + x`, generator_rrdb.py:134) */
     int32_t out_channels;  /* 1..1024 (models.toml: 1) */
-    int32_t num_filters;   /* 1..1024 (models.toml: filters = 32).  32, 64, 96 ... 256 filters (any multiple of 32) with up to 8 image channels in and out run on
-                              the split-precision MFMA kernels (a feature tensor = 1..8 planes of 32 channels); any other widths
-                              on the exact-fp32 kernels of csrc/generic_net.hip (xsd_set_math does not apply there) */
+    int32_t num_filters;   /* 1..1024 (models.toml: filters = 32).  up to 256 filters with up to 8 image channels in and out run on the
+                              split-precision MFMA kernels (a feature tensor = 1..8 planes of 32 channels; widths that are no
+                              multiple of 32 are zero-padded internally, the flat vectors keep the reference's layout); beyond
+                              that the exact-fp32 kernels of csrc/generic_net.hip (xsd_set_math does not apply there) */
     int32_t num_res_blocks;/* >= 1 (models.toml: residual_blocks = 4) */
     int32_t num_upsample;  /* SR only: (hr_res/lr_res)/2, 1 or 2 */
     int32_t memory_efficient; /* rrdb_blocks.py:39-47 recompute policy; numerics identical. Enforced by the host (chunked recompute), not here */

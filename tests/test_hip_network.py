@@ -295,7 +295,7 @@ def test_memory_efficient_recompute_matches_full_batch(kind, monkeypatch):
     from xmm_superres_denoise.parallel import DataParallelTrainer
     monkeypatch.setenv("XSD_ME_CHUNK", "2")
     torch.manual_seed(0)
-    ch = 2 if kind == "dn_16_filters_2_channels" else 1        # (the generic-width engine, csrc/generic_net.hip)
+    ch = 2 if kind == "dn_16_filters_2_channels" else 1        # (16 filters zero-padded to 32, two image channels: Builder::build_multi)
     mk = (lambda me: GeneratorRRDB_DN(1, 1, 32, 1, memory_efficient=me)) if kind == "dn" else \
          (lambda me: GeneratorRRDB_SR(1, 1, 32, 1, num_upsample=1, memory_efficient=me)) if kind == "sr" else \
          (lambda me: GeneratorRRDB_DN(1, 1, 64, 1, memory_efficient=me)) if kind == "dn_64_filters" else \
@@ -389,12 +389,16 @@ def test_backward_rejects_mismatched_dy_and_stale_generation():
     ("dn", 32, 2, 2, 2, 1, (1, 33, 20)),     # ... DN with its skip per channel
     ("dn", 64, 4, 4, 1, 1, (1, 12, 34)),
     ("dn", 32, 1, 3, 1, 1, (2, 17, 33)),     # ... and with a one-channel x broadcast over three output channels (generator_rrdb.py:134)
+    # what the plane kernels do not take stays on the exact-fp32 kernels of csrc/generic_net.hip:
+    ("dn", 8, 9, 9, 1, 1, (1, 19, 21)),      # more than 8 image channels: direct convolutions throughout
+    ("sr", 272, 1, 1, 1, 1, (1, 6, 9)),      # more than 256 filters: the fp32 matrix instruction with partial 32-channel blocks, 272 -> 1088 shuffle conv
+    ("dn", 20, 10, 10, 1, 1, (1, 17, 33)),   # ... both kinds of conv in one net (20-filter trunk on the matrix instruction, 10-channel image side direct)
 ])
 def test_generic_widths_vs_float64_restatement(kind, nf, in_ch, out_ch, blocks, nup, shape):
-    """Widths other than the shipped 32 / 1 / 1 (reference constructors take any: generator_rrdb.py:10-54) run on the
-    exact-fp32 kernels of csrc/generic_net.hip: convs with >= 16 channels on both sides on the fp32 matrix instruction (the
-    64-, 48- and 16-filter cases), narrower ones as direct convolutions.  Forward, dL/dx and every parameter gradient against a
-    float64 evaluation of the reference graph (oracle.torch_forward; the C oracle handles one image channel only), through
+    """Widths other than the shipped 32 / 1 / 1 (reference constructors take any: generator_rrdb.py:10-54).  Up to 256 filters
+    and 8 image channels run on the plane kernels (widths that are no multiple of 32 zero-padded: the 8-, 12-, 16-, 48-filter
+    cases; wider nets with several planes per tensor); beyond that the exact-fp32 kernels of csrc/generic_net.hip (convs with
+    >= 16 channels on both sides on the fp32 matrix instruction, narrower ones as direct convolutions).  Forward, dL/dx and every parameter gradient against a float64 evaluation of the reference graph (oracle.torch_forward; the C oracle handles one image channel only), through
     the nn.Module API, L1 loss."""
     _widths_vs_float64(kind, nf, in_ch, out_ch, blocks, nup, shape)
 

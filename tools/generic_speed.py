@@ -27,7 +27,7 @@ def run(nf, cin, cout, blocks, B, math=None):
     rdb = sum(conv(nf * k, nf) for k in range(1, 6))
     mac = conv(cin, nf) + blocks * 3 * rdb + conv(nf, nf) + conv(nf, cout)
     fl = 2 * mac * 512 * 512 * B
-    engine = "planes" if (cin == cout and cin <= 8 and nf % 32 == 0 and nf <= 256) else "generic fp32"
+    engine = ("planes" if nf % 32 == 0 else f"planes, padded to {(nf + 31) // 32 * 32}") if (cin <= 8 and cout <= 8 and nf <= 256) else "generic fp32"
     print(f"nf={nf} in={cin} out={cout} blocks={blocks} B={B} engine={engine} math={math or 'default'}: fwd {fwd*1e3:8.1f} ms = {fl/fwd/1e12:6.2f} TFLOP/s; "
           f"train step {st*1e3:8.1f} ms = {3*fl/st/1e12:6.2f} TFLOP/s ({B/st:.2f} tiles/s)", flush=True)
 
@@ -39,3 +39,6 @@ run(64, 1, 1, 4, 2)
 run(8, 1, 1, 4, 8)
 run(64, 1, 1, 4, 8)
 run(128, 1, 1, 4, 2)
+run(48, 1, 1, 4, 4)
+run(16, 1, 1, 4, 8)
+run(320, 1, 1, 1, 1)

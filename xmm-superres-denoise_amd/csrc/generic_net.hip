@@ -2,8 +2,8 @@
 //
 // The reference's constructors accept any widths (generator_rrdb.py:10-54; config/config.py:164-203 PositiveInt; the dense
 // block's own default is nf = 64, rrdb_blocks.py:23); the split-precision MFMA path of this library takes whole 32-channel
-// planes (32 filters = the shipped configuration, res/configs/models.toml, and 64, 96, ... 256 filters; up to 8 image channels).
-// Every other configuration runs here, in exact fp32
+// planes (32 filters = the shipped configuration, res/configs/models.toml; any width up to 256 filters, zero-padded to a multiple
+// of 32; up to 8 image channels).  What lies beyond runs here, in exact fp32
 // (the math mode of xsd_set_math does not apply), on NCHW tensors like the reference's: convs with at least 16 channels on
 // both sides on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32, an fmaf chain: gconv_mfma_kernel, gwgrad_mfma_kernel),
 // narrower ones (the image-side convs; every conv of an 8-filter net) as direct convolutions on the vector ALUs.  Same C

@@ -69,7 +69,18 @@ struct ProfRec { hipEvent_t a, b; double flop, bytes; int klass; };
 
 struct xsd_engine {
     xsd_config cfg;
-    GenericNet* generic = nullptr;   // widths the plane kernels do not take (generic_net.hip): filters that are no multiple of 32 or > 256, more than 8 image channels
+    GenericNet* generic = nullptr;   // what the plane kernels do not take (generic_net.hip): more than 256 filters, more than 8 image channels
+    // Widths that are no multiple of 32 run zero-padded to the next one: the engine is built for `nf_pad` filters over an internal,
+    // padded flat parameter vector (pad weights and biases 0 -> pad channels are exactly 0 everywhere, forward and backward); the
+    // caller's vectors keep the reference's layout for `cfg.num_filters` (pad_params_kernel expands, pad_grads_kernel gathers)
+    int nf_pad = 0;                  // 0: no padding
+    long long nparams_pad = 0;
+    float* params_pad = nullptr;
+    float* grads_pad = nullptr;
+    void* pad_descs = nullptr;       // PadDesc[npad]: first | dense blocks | trunk, last, up.., hr  (= backward stages last | 1..blocks | 0)
+    int npad = 0;
+    std::vector<long long> rrdb_begin_real;
+    long long nparams_real = 0;
     int planes = 1;                  // num_filters / 32: 32-channel planes per feature tensor (1 = the shipped configuration; 2..8: Builder::build_multi)
     long long nparams = 0;
     // flat-param offsets
@@ -952,6 +963,29 @@ static int ensure_plan(xsd_engine* e, int B, int H, int W, bool train)
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// zero-padded widths: expansion of the caller's parameters / gathering of the gradients
+// ------------------------------------------------------------------------------------------------------------
+struct PadDesc {
+    long long w_r, b_r, w_p, b_p;    // weight / bias offsets in the caller's (real) and in the padded flat vector
+    int cout_r, cin_r, cin_p;        // OIHW extents (cout_p never matters: output channel oc keeps its index)
+    int tin_r, tin_p;                // width of the tensors the input is concatenated from: input channel t*tin_r + k <-> t*tin_p + k
+};
+__global__ void pad_params_kernel(const float* real, float* padded, const PadDesc* descs, int to_real /* 0: expand params, 1: gather grads */)
+{
+    const PadDesc d = descs[blockIdx.y];
+    const long long nw = (long long)d.cout_r * d.cin_r * 9;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nw + d.cout_r; e += (long long)gridDim.x * blockDim.x) {
+        long long r, q;
+        if (e < nw) {
+            const int tap = (int)(e % 9), ic = (int)((e / 9) % d.cin_r), oc = (int)(e / (9ll * d.cin_r));
+            const int icp = (ic / d.tin_r) * d.tin_p + ic % d.tin_r;
+            r = d.w_r + e; q = d.w_p + ((long long)oc * d.cin_p + icp) * 9 + tap;
+        } else { r = d.b_r + (e - nw); q = d.b_p + (e - nw); }
+        if (to_real) const_cast<float*>(real)[r] = padded[q]; else padded[q] = real[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------
 extern "C" {
@@ -978,12 +1012,11 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(XSD_ERR_HIP, "no HIP device available");
     xsd_engine* e = new xsd_engine();
     e->cfg = *cfg;
-    // whole 32-channel planes, a few image channels
-    const bool plane_path = cfg->num_filters % 32 == 0 && cfg->num_filters <= 256 && cfg->in_channels <= 8 && cfg->out_channels <= 8 &&
+    // 32-channel planes (widths that are no multiple of 32 zero-padded to the next one), a few image channels
+    const bool plane_path = cfg->num_filters <= 256 && cfg->in_channels <= 8 && cfg->out_channels <= 8 &&
                             (cfg->kind == XSD_KIND_SR || cfg->in_channels == cfg->out_channels || cfg->in_channels == 1);
     if (!plane_path) {
-        // neither the shipped configuration (res/configs/models.toml: 32 filters, one image channel) nor a wider net of whole 32-channel
-        // planes (64, 96, ... 256 filters: the dense block's own default is 64, rrdb_blocks.py:23): the generic-width path
+        // more than 256 filters or more than 8 image channels: the generic-width path (exact fp32)
         e->generic = GenericNet::create(*cfg);
         if (!e->generic) { delete e; return fail(XSD_ERR_NOMEM, "generic-width engine: device allocation failed"); }
         e->nparams = e->generic->nparams;
@@ -1002,20 +1035,31 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
         else { delete e; return fail(XSD_ERR_ARG, "XSD_MATH=%s: the math modes are fp32, bf16x6 and f16x3", m); }
     }
     const int blocks = cfg->num_res_blocks, nup = cfg->kind == XSD_KIND_SR ? cfg->num_upsample : 0;
-    const int nf = cfg->num_filters;
+    const int nf_r = cfg->num_filters, nf = (nf_r + 31) / 32 * 32;      // real / padded width
+    const int CIc = cfg->in_channels, COc = cfg->out_channels;
     e->planes = nf / 32;
-    long long off = 0, pk = 0, sb = 0;
-    take_conv(off, nf, cfg->in_channels, e->first_w, e->first_b);
+    if (nf != nf_r) e->nf_pad = nf;
+    long long off = 0, pk = 0, sb = 0, off_r = 0;
+    std::vector<PadDesc> pads;      // every conv in parameter order, with its place in the caller's (real-width) flat vector
+    auto pad_add = [&](long long w_p, long long b_p, int cout_r, int cin_r, int cin_p, int tin_r, int tin_p) {
+        PadDesc d; d.w_p = w_p; d.b_p = b_p; d.w_r = off_r; off_r += (long long)cout_r * cin_r * 9; d.b_r = off_r; off_r += cout_r;
+        d.cout_r = cout_r; d.cin_r = cin_r; d.cin_p = cin_p; d.tin_r = tin_r; d.tin_p = tin_p;
+        pads.push_back(d);
+    };
+    take_conv(off, nf, CIc, e->first_w, e->first_b);
+    pad_add(e->first_w, e->first_b, nf_r, CIc, CIc, CIc, CIc);
     auto mk = [&](int cout, int cin, int shuffle) {
         ConvW c; take_conv(off, cout, cin, c.w_off, c.b_off);
         c.cout = cout; c.cin = cin; c.shuffle = shuffle;
         c.fwd_off = pk; c.bwd_off = pk; pk += (long long)(cout / 32) * (cin / 32) * PANEL_FLOATS;
         c.sbias_off = -1;
         if (shuffle) { c.sbias_off = sb; sb += cout; }
+        pad_add(c.w_off, c.b_off, cout / nf * nf_r, cin / nf * nf_r, cin, nf_r, nf);      // cout, cin are multiples of the (padded) width
         return c;
     };
     for (int i = 0; i < blocks; ++i) {
         e->rrdb_begin.push_back(off);
+        e->rrdb_begin_real.push_back(off_r);
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 5; ++c) {
                 e->rdb.push_back(mk(nf, nf * (c + 1), 0));
@@ -1024,11 +1068,16 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
             }
     }
     e->rrdb_begin.push_back(off);
+    e->rrdb_begin_real.push_back(off_r);
     e->trunk = mk(nf, nf, 0);
-    take_conv(off, cfg->out_channels, nf, e->last_w, e->last_b);
+    take_conv(off, COc, nf, e->last_w, e->last_b);
+    pad_add(e->last_w, e->last_b, COc, nf_r, nf, nf_r, nf);
     for (int u = 0; u < nup; ++u) e->up.push_back(mk(4 * nf, nf, 1));
     if (cfg->kind == XSD_KIND_SR) e->hr = mk(nf, nf, 0);
-    e->nparams = off;
+    e->nparams_pad = off;
+    e->nparams_real = off_r;
+    e->npad = (int)pads.size();
+    e->nparams = e->nf_pad ? off_r : off;       // what the caller's flat vectors hold
     e->pk_floats = pk;
 
     std::vector<PackDesc> descs;
@@ -1043,6 +1092,12 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     CK(hipMalloc((void**)&e->pk_bwd, sizeof(float) * pk));
     CK(hipMalloc((void**)&e->pk_fwd_s, sizeof(float) * pk));
     CK(hipMalloc((void**)&e->pk_bwd_s, sizeof(float) * pk));
+    if (e->nf_pad) {
+        CK(hipMalloc((void**)&e->params_pad, sizeof(float) * e->nparams_pad));
+        CK(hipMalloc((void**)&e->grads_pad, sizeof(float) * e->nparams_pad));
+        CK(hipMalloc((void**)&e->pad_descs, sizeof(PadDesc) * pads.size()));
+        CK(hipMemcpy(e->pad_descs, pads.data(), sizeof(PadDesc) * pads.size(), hipMemcpyHostToDevice));
+    }
     CK(hipMalloc((void**)&e->amax, sizeof(float) * xsd_engine::AMAX_CAP));
     CK(hipMemset(e->amax, 0, sizeof(float) * xsd_engine::AMAX_CAP));
     CK(hipMalloc((void**)&e->zero_page, 512));   // [0,256): zeros (padding source); [256,512): trash (stores of lanes outside the image)
@@ -1068,7 +1123,7 @@ void xsd_destroy(xsd_engine* e)
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     hipFree(e->pk_fwd); hipFree(e->pk_bwd); hipFree(e->pk_fwd_s); hipFree(e->pk_bwd_s); hipFree(e->zero_page); hipFree(e->amax); hipFree(e->pk_edge); hipFree(e->pk_sbias); hipFree(e->descs_dev);
     hipFree(e->wg_partial); hipFree(e->wg_bias_partial); hipFree(e->edge_partial); hipFree(e->loss_partial);
-    hipFree(e->ws);
+    hipFree(e->ws); hipFree(e->params_pad); hipFree(e->grads_pad); hipFree(e->pad_descs);
     delete e;
 }
 
@@ -1089,6 +1144,13 @@ int xsd_pack_weights(xsd_engine* e, const float* dev_params, void* stream)
     hipStream_t s = (hipStream_t)stream;
     e->params = dev_params;
     if (e->generic) { HIPCHK(e->generic->pack(dev_params, s)); e->packed = true; return XSD_OK; }
+    if (e->nf_pad) {     // the engine runs on the zero-padded copy
+        HIPCHK(hipMemsetAsync(e->params_pad, 0, sizeof(float) * e->nparams_pad, s));
+        hipLaunchKernelGGL(pad_params_kernel, dim3(64, e->npad), dim3(256), 0, s, dev_params, e->params_pad, static_cast<const PadDesc*>(e->pad_descs), 0);
+        HIPCHK(hipGetLastError());
+        dev_params = e->params_pad;
+        e->params = dev_params;
+    }
     if (e->math == 4) {
         // fp32 fragment-order panels into the (otherwise unused) mode-0 buffers, max |w| of the forward and of the
         // input-gradient panels (one power-of-two scale each), then the two-term fp16 images the conv kernel copies to LDS
@@ -1163,8 +1225,17 @@ int xsd_backward_stage(xsd_engine* e, int stage, const float* dev_dy, float* dev
     }
     if (stage < 0 || stage >= (int)e->bwd_stages.size()) return fail(XSD_ERR_ARG, "stage %d out of range", stage);
     hipStream_t s = (hipStream_t)stream;
-    e->b_dy = dev_dy; e->b_dx = dev_dx_or_null; e->b_grads = dev_grads;
+    e->b_dy = dev_dy; e->b_dx = dev_dx_or_null; e->b_grads = e->nf_pad ? e->grads_pad : dev_grads;
     for (auto& op : e->bwd_stages[stage]) HIPCHK(op(s));
+    if (e->nf_pad) {     // this stage's convs from the padded gradient into the caller's vector
+        const int blocks = e->cfg.num_res_blocks;
+        int d0, d1;
+        if (stage == blocks + 1) { d0 = 0; d1 = 1; }                                   // conv_first
+        else if (stage >= 1) { const int i = blocks - stage; d0 = 1 + 15 * i; d1 = d0 + 15; }   // dense blocks of rrdb.i
+        else { d0 = 1 + 15 * blocks; d1 = e->npad; }                                  // trunk, conv_last, upsampling, HRconv
+        hipLaunchKernelGGL(pad_params_kernel, dim3(64, d1 - d0), dim3(256), 0, s, dev_grads, e->grads_pad, static_cast<const PadDesc*>(e->pad_descs) + d0, 1);
+        HIPCHK(hipGetLastError());
+    }
     return XSD_OK;
 }
 
@@ -1190,9 +1261,10 @@ int xsd_grad_range(const xsd_engine* e, int stage, int range_idx, int64_t* offse
         if (count) *count = b;
         return 1;
     }
-    if (stage == 0) { a = e->rrdb_begin[blocks]; b = e->nparams; }
-    else if (stage <= blocks) { const int i = blocks - stage; a = e->rrdb_begin[i]; b = e->rrdb_begin[i + 1]; }
-    else { a = 0; b = e->rrdb_begin[0]; }
+    const std::vector<long long>& rb = e->nf_pad ? e->rrdb_begin_real : e->rrdb_begin;   // offsets in the caller's vector
+    if (stage == 0) { a = rb[blocks]; b = e->nparams; }
+    else if (stage <= blocks) { const int i = blocks - stage; a = rb[i]; b = rb[i + 1]; }
+    else { a = 0; b = rb[0]; }
     if (offset) *offset = a;
     if (count) *count = b - a;
     return 1;

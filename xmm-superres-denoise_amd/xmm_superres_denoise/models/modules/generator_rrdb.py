@@ -120,8 +120,8 @@ class _GeneratorRRDB(nn.Module):
                  memory_efficient: bool = False):
         super().__init__()
         # Any widths, like the reference (generator_rrdb.py:10-54).  The shipped configuration (res/configs/models.toml: 32
-        # filters, one image channel), 64, 96, ... 256 filters and up to 8 image channels run on the split-precision MFMA kernels; every other one on
-        # the exact-fp32 kernels of csrc/generic_net.hip.  What cannot work is said HERE, not at the first forward.
+        # filters, one image channel), every width up to 256 filters and up to 8 image channels run on the split-precision MFMA
+        # kernels; beyond that the exact-fp32 kernels of csrc/generic_net.hip.  What cannot work is said HERE, not at the first forward.
         for name, v in (("in_channels", in_channels), ("out_channels", out_channels), ("num_filters", num_filters)):
             if not 1 <= int(v) <= 1024:
                 raise ValueError(f"{name} must be in [1, 1024] (got {v})")
