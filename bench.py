@@ -379,6 +379,8 @@ def main():
                        "math": args.math,
                        "parallelism": f"dp{world}", "dist_backend": backend if world > 1 else None},
         }
+        if NF % 32:
+            out["config"]["runs_zero_padded_to_filters"] = (NF + 31) // 32 * 32      # the kernels' flop / byte counts below are those of the padded width
         if replicas_identical is not None:
             out["replicas_identical"] = replicas_identical
         if prof is not None and prof[0]["launches"] > 0:
