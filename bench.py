@@ -110,7 +110,7 @@ def pmc_traffic(math: str, batch: int, klass: str):
     """HBM bytes per launch from the committed PMC passes (tools/traffic.sh -> profiles/rNN_traffic_<math>.json, newest round
     first), valid only for the workload/batch they were collected on.  Returns (bytes, file) or (None, None): the figure is
     READ FROM THAT FILE, not measured in this run (PMC passes need rocprofv3 around the process)."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         rel = os.path.join("profiles", f"{rnd}_traffic_{math}.json")
         try:
             d = json.load(open(os.path.join(ROOT, rel)))
@@ -236,8 +236,12 @@ def main():
     dev_index = local_rank % ndev if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # XSD_FORCE_DP=1 with one rank: a one-rank process group, every collective line of this file and of parallel.py executes
+    # (tests/test_hip_parallel.py runs it over RCCL on the single MI355X -- the code a multi-GPU node takes)
+    dp = world > 1 or os.environ.get("XSD_FORCE_DP", "0") == "1"
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -277,6 +281,10 @@ def main():
         loss_fn = create_loss(*load_loss_config("linear"))
     trainer = DataParallelTrainer(model, lr=1e-4, betas=(0.9, 0.999), loss=loss_fn)
     eng = trainer.engine
+    run_math = eng.get_math()     # what the kernels compute in: widths beyond the plane kernels (> 256 filters) run exact fp32 whatever --math says
+    if run_math != args.math:
+        print(f"bench.py: --filters {NF} runs on the exact-fp32 kernels; labelling this run '{run_math}', not '{args.math}'", file=sys.stderr)
+        args.math = run_math
     trace("trainer built (parameters broadcast)")
 
     counts = mask = None
@@ -308,7 +316,7 @@ def main():
             trace(f"warm-up step {i} enqueued")
         if profile:
             eng.profile_enable(True)
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
         trace("timed region starts")
@@ -317,10 +325,10 @@ def main():
             step()
         torch.cuda.synchronize()
         trace("timed region done")
-        if world > 1:
+        if dp:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dp:
             tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -333,7 +341,7 @@ def main():
     dt, prof = timed(args.warmup, args.steps, not args.no_profile)
 
     replicas_identical = None
-    if world > 1 and train:     # DDP invariant, checked outside the timed region: every rank holds bit-identical parameters
+    if dp and train:     # DDP invariant, checked outside the timed region: every rank holds bit-identical parameters
         bits = trainer.flat.view(torch.int32).to(torch.int64)
         h = torch.stack([bits.sum(), (bits * torch.arange(1, bits.numel() + 1, device=dev, dtype=torch.int64)).sum()])   # (wraps: fine, it is a hash)
         hs = [torch.zeros_like(h) for _ in range(world)]
@@ -377,7 +385,7 @@ def main():
                        "tile": f"1x{TILE}x{TILE}", "per_gpu_batch": B, "global_batch": B * world,
                        "layers": "RRDB generator, 32 filters x 4 blocks (res/configs/models.toml)" if NF == 32 else f"RRDB generator, {NF} filters x 4 blocks (NOT the BASELINE width)",
                        "math": args.math,
-                       "parallelism": f"dp{world}", "dist_backend": backend if world > 1 else None},
+                       "parallelism": f"dp{world}", "dist_backend": backend if dp else None},
         }
         if NF % 32:
             out["config"]["runs_zero_padded_to_filters"] = (NF + 31) // 32 * 32      # the kernels' flop / byte counts below are those of the padded width
@@ -390,7 +398,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and NF == 32:
             out["cpu_baseline"] = cpu_baseline(kind, train)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

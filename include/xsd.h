@@ -79,6 +79,8 @@ int64_t xsd_param_count(const xsd_engine* e);
  * Modes 3 and 4 address a plane's batch slice with 32-bit byte offsets: images of 2^24 or more output pixels are rejected
  * by xsd_forward (mode 0 takes them). */
 int xsd_set_math(xsd_engine* e, int mode);
+/* The mode the kernels of THIS engine compute in: the setting above on the plane kernels; 0 on the exact-fp32 path that serves
+ * more than 256 filters / more than 8 image channels, whatever was set. */
 int xsd_get_math(const xsd_engine* e);
 
 /* Repack the caller's flat OIHW parameters into MFMA fragment-order panels (forward + transposed/flipped for the

@@ -36,7 +36,12 @@ def lib():
         fp = ctypes.POINTER(ctypes.c_float)
         L.xsd_oracle_param_count.restype = ctypes.c_long
         L.xsd_oracle_param_count.argtypes = [ctypes.c_int] * 4
+        L.xsd_oracle_param_count_c.restype = ctypes.c_long
+        L.xsd_oracle_param_count_c.argtypes = [ctypes.c_int] * 6
         L.xsd_oracle_forward.argtypes = [ctypes.c_int] * 4 + [fp, fp] + [ctypes.c_int] * 3 + [fp]
+        L.xsd_oracle_forward_c.argtypes = [ctypes.c_int] * 6 + [fp, fp] + [ctypes.c_int] * 3 + [fp]
+        L.xsd_oracle_l1_train_c.argtypes = ([ctypes.c_int] * 6 + [fp, fp, fp] + [ctypes.c_int] * 3 +
+                                            [fp, ctypes.POINTER(ctypes.c_double), fp, fp])
         L.xsd_oracle_l1_train.argtypes = ([ctypes.c_int] * 4 + [fp, fp, fp] + [ctypes.c_int] * 3 +
                                           [fp, ctypes.POINTER(ctypes.c_double), fp, fp])
         L.xsd_oracle_conv3x3.argtypes = [fp, fp, fp, fp] + [ctypes.c_int] * 5
@@ -71,30 +76,37 @@ def unflatten(flat: np.ndarray, shapes) -> dict:
     return out
 
 
-def forward(kind, nf, blocks, params, x, num_upsample=1):
+def forward(kind, nf, blocks, params, x, num_upsample=1, out_ch=1):
+    """x: [B, in_ch, H, W] -> [B, out_ch, sH, sW]; any image channel counts the reference's constructors take
+    (generator_rrdb.py:10-16; DN: in_ch == out_ch, or a one-channel x broadcast by `out + x`, :134)"""
     x = _f32(x)
     B, C, H, W = x.shape
-    assert C == 1
     s = 2 ** num_upsample if kind == "sr" else 1
-    y = np.empty((B, 1, H * s, W * s), np.float32)
+    y = np.empty((B, out_ch, H * s, W * s), np.float32)
     params = _f32(params)
-    assert params.size == lib().xsd_oracle_param_count(KIND[kind], nf, blocks, num_upsample)
-    lib().xsd_oracle_forward(KIND[kind], nf, blocks, num_upsample, _p(params), _p(x), B, H, W, _p(y))
+    assert params.size == lib().xsd_oracle_param_count_c(KIND[kind], nf, blocks, num_upsample, C, out_ch)
+    rc = lib().xsd_oracle_forward_c(KIND[kind], nf, blocks, num_upsample, C, out_ch, _p(params), _p(x), B, H, W, _p(y))
+    if rc != 0:
+        raise ValueError(f"oracle: a DN generator cannot add a {C}-channel input to {out_ch} output channels")
     return y
 
 
 def l1_train(kind, nf, blocks, params, x, target, num_upsample=1):
-    """returns y, loss, dx, flat grads"""
+    """returns y, loss, dx, flat grads; the channel counts are read off x and target"""
     x, target, params = _f32(x), _f32(target), _f32(params)
     B, C, H, W = x.shape
+    out_ch = target.shape[1]
     s = 2 ** num_upsample if kind == "sr" else 1
-    assert target.shape == (B, 1, H * s, W * s)
+    assert target.shape == (B, out_ch, H * s, W * s)
+    assert params.size == lib().xsd_oracle_param_count_c(KIND[kind], nf, blocks, num_upsample, C, out_ch)
     y = np.empty_like(target)
     dx = np.empty_like(x)
     grads = np.zeros_like(params)
     loss = ctypes.c_double(0.0)
-    lib().xsd_oracle_l1_train(KIND[kind], nf, blocks, num_upsample, _p(params), _p(x), _p(target), B, H, W,
-                              _p(y), ctypes.byref(loss), _p(dx), _p(grads))
+    rc = lib().xsd_oracle_l1_train_c(KIND[kind], nf, blocks, num_upsample, C, out_ch, _p(params), _p(x), _p(target), B, H, W,
+                                     _p(y), ctypes.byref(loss), _p(dx), _p(grads))
+    if rc != 0:
+        raise ValueError(f"oracle: a DN generator cannot add a {C}-channel input to {out_ch} output channels")
     return y, loss.value, dx, grads
 
 

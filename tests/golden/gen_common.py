@@ -46,11 +46,11 @@ def rrdb_param_shapes(kind: str, nf: int, blocks: int, in_ch: int = 1, out_ch: i
 
 
 def make_state(kind: str, nf: int, blocks: int, seed: int, num_upsample: int = 1,
-               gain: float = 1.0, last_bias: float | None = None) -> "OrderedDict[str, np.ndarray]":
+               gain: float = 1.0, last_bias: float | None = None, in_ch: int = 1, out_ch: int = 1) -> "OrderedDict[str, np.ndarray]":
     """Deterministic fp32 weights: U(-b, b), b = gain/sqrt(fan_in), drawn in state-dict order."""
     rng = np.random.default_rng(seed)
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
-    shapes = rrdb_param_shapes(kind, nf, blocks, num_upsample=num_upsample)
+    shapes = rrdb_param_shapes(kind, nf, blocks, in_ch=in_ch, out_ch=out_ch, num_upsample=num_upsample)
     fan_in = 1
     for name, shp in shapes.items():
         if name.endswith(".weight"):

@@ -60,11 +60,12 @@ def import_reference():
     return rb, gen, ref_transforms, tools
 
 
-def build_ref(gen, kind, nf, blocks, num_upsample=1):
+def build_ref(gen, kind, nf, blocks, num_upsample=1, in_ch=1, out_ch=1):
+    """the reference's own constructors (generator_rrdb.py:73-81,114-121) at any widths / image channel counts"""
     if kind == "dn":
-        m = gen.GeneratorRRDB_DN(1, 1, nf, blocks)
+        m = gen.GeneratorRRDB_DN(in_ch, out_ch, nf, blocks)
     else:
-        m = gen.GeneratorRRDB_SR(1, 1, nf, blocks, num_upsample=num_upsample)
+        m = gen.GeneratorRRDB_SR(in_ch, out_ch, nf, blocks, num_upsample=num_upsample)
     return m
 
 
@@ -77,14 +78,17 @@ def load_np_state(m, state):
 
 
 def run_case(gen, name, kind, nf, blocks, xshape, wseed, xseed, tseed, num_upsample=1,
-             full_grads=False, last_bias=None, selected=()):
+             full_grads=False, last_bias=None, selected=(), out_ch=1):
+    """xshape = (B, in_ch, H, W); out_ch output channels (the target's).  Cases with image channel counts other than 1 / 1
+    store them under "chan"."""
     torch.manual_seed(0)
-    m = build_ref(gen, kind, nf, blocks, num_upsample)
-    state = gc.make_state(kind, nf, blocks, wseed, num_upsample=num_upsample, last_bias=last_bias)
+    in_ch = xshape[1]
+    m = build_ref(gen, kind, nf, blocks, num_upsample, in_ch, out_ch)
+    state = gc.make_state(kind, nf, blocks, wseed, num_upsample=num_upsample, last_bias=last_bias, in_ch=in_ch, out_ch=out_ch)
     load_np_state(m, state)
     x = torch.from_numpy(gc.make_input(xshape, xseed)).requires_grad_(True)
     scale = 1 if kind == "dn" else 2 ** num_upsample
-    tshape = (xshape[0], 1, xshape[2] * scale, xshape[3] * scale)
+    tshape = (xshape[0], out_ch, xshape[2] * scale, xshape[3] * scale)
     t = torch.from_numpy(gc.make_input(tshape, tseed))
     # Model.forward clamps a second time (models/model.py:48-49)
     y = torch.clamp(m(x), min=0.0, max=1.0)
@@ -93,6 +97,8 @@ def run_case(gen, name, kind, nf, blocks, xshape, wseed, xseed, tseed, num_upsam
     out = OrderedDict()
     out["meta"] = np.array([nf, blocks, num_upsample, wseed, xseed, tseed] + list(xshape), dtype=np.int64)
     out["last_bias"] = np.array([np.nan if last_bias is None else last_bias], dtype=np.float64)
+    if (in_ch, out_ch) != (1, 1):
+        out["chan"] = np.array([in_ch, out_ch], dtype=np.int64)
     out["y"] = y.detach().numpy()
     out["loss"] = np.array([loss.item()], dtype=np.float64)
     out["dx"] = x.grad.numpy()
@@ -247,9 +253,25 @@ def example_data_golden(gen, ref_transforms, tools):
     np.savez_compressed(os.path.join(HERE, "example_data.npz"), **out)
 
 
+def width_cases(gen):
+    """Round 4: the reference at OTHER widths and image channel counts than the shipped 32 / 1 / 1 (its constructors take any,
+    generator_rrdb.py:10-54; the dense block's own default is nf = 64, rrdb_blocks.py:23), so that the engine's multi-plane,
+    zero-padded and per-image-channel paths are pinned to the reference itself rather than to a restatement.  Small images;
+    the wide nets keep full tensors of a selection of layers plus the per-tensor sums of every gradient."""
+    sel = ("conv_first", "conv_last", "trunk_conv", "rrdb.0.RDB1.conv1", "rrdb.0.RDB2.conv3", "rrdb.0.RDB3.conv5", "upsampling.3", "HRconv")
+    run_case(gen, "dn_nf64_b1", "dn", 64, 1, (1, 1, 20, 24), 101, 102, 103, selected=sel)                        # two planes per tensor
+    run_case(gen, "sr_nf32_c3x2_b1", "sr", 32, 1, (2, 3, 18, 35), 111, 112, 113, full_grads=True, last_bias=0.4, out_ch=2)   # RGB in, 2 out
+    run_case(gen, "dn_nf16_c1x3_b1", "dn", 16, 1, (2, 1, 16, 16), 121, 122, 123, full_grads=True, out_ch=3)      # broadcast skip (:134), zero-padded width
+    run_case(gen, "sr_nf64_b1_up2", "sr", 64, 1, (1, 1, 9, 11), 131, 132, 133, num_upsample=2, selected=sel, last_bias=0.4)
+    run_case(gen, "dn_nf48_b1", "dn", 48, 1, (1, 1, 21, 45), 141, 142, 143, selected=sel)                        # zero-padded to 64: two planes, one half empty
+
+
 def main():
     torch.set_num_threads(8)
     rb, gen, ref_transforms, tools = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "widths":      # only the round-4 additions (the older fixtures stay byte-identical)
+        return width_cases(gen)
+    width_cases(gen)
     init_parity(gen)
     transforms_golden(ref_transforms, tools)
     sel = ("conv_first", "conv_last", "trunk_conv", "rrdb.0.RDB1.conv1", "rrdb.0.RDB1.conv5",

@@ -103,3 +103,33 @@ def test_input_pipeline_train_step_full_size():
     l0 = float(tr.train_step(compose_input(counts, None, None, mask, 512, 0.0022336, "sqrt"), t))
     l1 = float(tr.train_step(compose_input(counts, None, None, mask, 512, 0.0022336, "sqrt"), t))
     assert np.isfinite([l0, l1]).all() and l1 < l0 + 1e-4
+
+
+@pytest.mark.parametrize("math", ["f16x3", "bf16x6", "fp32"])
+def test_backward_is_batch_independent_at_the_bench_batch(math):
+    """BASELINE configs[2] batch (32 tiles of 512 x 512, 4 blocks): the input gradient of a tile must not depend on its batch
+    neighbours.  dL/dx of tiles 0, 13 and 31 out of the batch-32 backward equals, BITWISE, the dL/dx the same tiles get in a
+    batch of their own (the forward's batch independence is asserted in test_hip_network.py; this is the backward's, at the
+    batch where every persistent workgroup walks 64 tiles across many batch slices).  The parameter gradients of the small
+    batch are a partial sum of the big one's and only bound it."""
+    state = gc.make_state("dn", 32, 4, 31337)
+    m = build_module("dn", 4, 1, state).set_math(math)
+    eng = m._get_engine(torch.device("cuda", 0))
+    eng.pack(m.flat_parameters())
+    B = 32
+    x = _tiles((B, 1, 512, 512), 5).cuda()
+    dy = ((_tiles((B, 1, 512, 512), 6) - 0.5) / (B * 512 * 512)).cuda()
+    y = eng.forward(x, save_for_backward=True)
+    g = torch.empty_like(m.flat_parameters())
+    dx = eng.backward(dy, g, need_dx=True).clone()
+    y = y.clone()
+    assert torch.isfinite(dx).all() and torch.isfinite(g).all()
+    pick = [0, 13, 31]
+    xs, dys = x[pick].contiguous(), dy[pick].contiguous()
+    del x, dy
+    y3 = eng.forward(xs, save_for_backward=True)
+    g3 = torch.empty_like(g)
+    dx3 = eng.backward(dys, g3, need_dx=True)
+    assert torch.equal(y3, y[pick])
+    assert torch.equal(dx3, dx[pick])
+    assert float(g3.abs().max()) <= float(g.abs().max()) * 3.0 + 1e-30

@@ -106,6 +106,28 @@ def test_error_behaviour():
         Loss({"l1": 1.0})(torch.rand(1, 1, 8, 8), torch.rand(1, 1, 8, 8))   # CPU tensors: no fallback
 
 
+def test_multi_channel_images_fold_into_the_batch():
+    """Generators with out_channels > 1 (the reference's constructors take any, generator_rrdb.py:10-16): the element-wise terms
+    and ssim over [B, C, H, W] equal the same terms over the B*C one-channel images (what torchmetrics computes for them);
+    ms_ssim, whose per-scale channel reduction that fold does not reproduce, is refused with a message."""
+    from xmm_superres_denoise.engine import XsdError
+    from xmm_superres_denoise.utils import Loss
+    rng = np.random.default_rng(9)
+    p = rng.uniform(0, 1, size=(2, 3, 40, 56)).astype(np.float32)
+    t = rng.uniform(0, 1, size=(2, 3, 40, 56)).astype(np.float32)
+    w = {"l1": 0.4, "poisson": 0.1, "psnr": 0.2, "ssim": 0.3}
+    tot, vals, dy = _run(w, 0.0, p, t)
+    tot1, vals1, dy1 = _run(w, 0.0, p.reshape(6, 1, 40, 56), t.reshape(6, 1, 40, 56))
+    assert tot == tot1 and vals == vals1 and np.array_equal(dy.reshape(dy1.shape), dy1)
+    # and against the float64 oracle, term by term, on the folded images
+    for term in w:
+        v, g = ol._FUNCS[term](p.reshape(6, 40, 56), t.reshape(6, 40, 56))
+        assert abs(vals[term] - v) <= VAL_RTOL * max(1.0, abs(v)), term
+    f = Loss({"ms_ssim": 1.0}, 0.0)
+    with pytest.raises(XsdError, match="ms_ssim over 3-channel"):
+        f.value_and_grad(torch.from_numpy(p).cuda(), torch.from_numpy(t).cuda())
+
+
 def test_full_size_properties():
     """512 x 512, batch 8: identical images give ssim = ms_ssim = 1 and a vanishing gradient; the composed value is
     linear in the weights; the result is bit-reproducible (deterministic reductions)."""

@@ -15,9 +15,12 @@ pytestmark = pytest.mark.gpu
 
 CASES = [("dn_nf32_b4_32x32", "dn"), ("dn_nf32_b4_24x40", "dn"), ("sr_nf32_b4_24x40", "sr"),
          ("sr_nf32_b4_17x45", "sr"), ("dn_nf32_b1_64x64", "dn")]
-# the reference's goldens at another width (8 filters: reduced model of SURVEY 7.1; full gradient tensors stored): the
-# generic-width path of the library (csrc/generic_net.hip, exact fp32, every math mode setting)
+# the reference's goldens at other widths: 8 filters (reduced model of SURVEY 7.1; full gradient tensors stored; runs
+# zero-padded to one plane on the split-precision kernels since round 3) and the round-4 set generated from the reference's own
+# constructors at 64 / 48 / 16 filters and 3 -> 2 / 1 -> 3 image channels (tests/golden/make_golden.py:width_cases) -- every
+# one of them in every math mode, held to the same flip-aware bar as the shipped width
 NF8_CASES = [("dn_nf8_b1", "dn"), ("sr_nf8_b1", "sr"), ("sr_nf8_b1_up2", "sr")]
+WIDTH_CASES = [("dn_nf64_b1", "dn"), ("sr_nf32_c3x2_b1", "sr"), ("dn_nf16_c1x3_b1", "dn"), ("sr_nf64_b1_up2", "sr"), ("dn_nf48_b1", "dn")]
 
 
 def _relmax(a, b):
@@ -39,10 +42,10 @@ def _report_flips(tag, before):
                                                    f"{r['unexplained']} unexplained (max {r['max_rel_err']:.1e})" for r in recs))
 
 
-@pytest.mark.parametrize("name,kind,math", [(n, k, m) for n, k in CASES for m in MATHS] + [(n, k, "fp32") for n, k in NF8_CASES])
+@pytest.mark.parametrize("name,kind,math", [(n, k, m) for n, k in CASES + NF8_CASES + WIDTH_CASES for m in MATHS])
 def test_golden_forward_backward(name, kind, math):
     z, nf, blocks, nup, state, x, t = load_case(name, kind)
-    m = build_module(kind, blocks, nup, state, nf=nf).set_math(math)
+    m = build_module(kind, blocks, nup, state, nf=nf, in_ch=x.shape[1], out_ch=t.shape[1]).set_math(math)
     xd = torch.from_numpy(x).cuda().requires_grad_(True)
     y = m(xd)
     assert np.abs(y.detach().cpu().numpy() - z["y"]).max() < 1e-4
@@ -433,10 +436,15 @@ def _widths_vs_float64(kind, nf, in_ch, out_ch, blocks, nup, shape, math=None):
     loss = torch.nn.functional.l1_loss(y, torch.from_numpy(t).cuda())
     assert abs(loss.item() - l64.item()) < 1e-5
     loss.backward()
-    cand_tol = dict(tight=2e-4, loose=5e-2, max_flip_frac=0.3)
-    assert_grad_close(xd.grad.cpu().numpy().reshape(-1, W), x64.grad.numpy().reshape(-1, W), "dx", **cand_tol)
+    # flip-aware, like the shipped width (round 3 allowed 30 % of a tensor's rows to exceed the tight bar here): only the rows a
+    # float64 evaluation names as flip candidates (a pre-activation within 4e-6 rms of zero in that conv's output channel)
+    # may exceed 2e-4 of the tensor's largest entry; everything else must explain itself
+    cand, n_out = flip_candidates(kind, blocks, state, x, t, nup)
+    mark = len(FLIP_LOG)
+    assert_grad_close(xd.grad.cpu().numpy().reshape(-1, W), x64.grad.numpy().reshape(-1, W), "dx", tight=4e-4, loose=5e-2, candidates=cand, n_out_candidates=n_out)
     for n, p in m.named_parameters():
-        assert_grad_close(p.grad.cpu().numpy(), st64[n].grad.numpy(), n, **cand_tol)
+        assert_grad_close(p.grad.cpu().numpy(), st64[n].grad.numpy(), n, tight=2e-4, loose=5e-2, candidates=cand, n_out_candidates=n_out)
+    _report_flips(f"{kind} nf={nf} {in_ch}->{out_ch} nup={nup} {math or 'default'}", mark)
     # and without autograd (no activations kept: two slabs ping-pong) the same output, bit for bit
     with torch.no_grad():
         assert torch.equal(m(xd.detach()), y.detach())

@@ -25,12 +25,12 @@ def _free_port():
     return p
 
 
-def _launch(out_dir, world, backend, steps, math, kind="dn"):
+def _launch(out_dir, world, backend, steps, math, kind="dn", extra_env=None):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(out_dir), backend, str(steps), math, kind],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
@@ -76,13 +76,76 @@ def test_two_ranks_on_hip_engine_match_single_process_full_batch(tmp_path, math,
     assert np.abs(res[0]["params"][-1] - res[0]["params"][0]).max() > 1e-4
 
 
+@pytest.mark.parametrize("math,kind", [("f16x3", "dn"), ("bf16x6", "sr")])
+def test_rccl_branch_on_one_gpu_is_bit_equal_to_the_plain_step(tmp_path, math, kind):
+    """The code a multi-GPU node runs, executed on the single MI355X: backend "nccl" (= RCCL) with a ONE-rank process group and
+    XSD_FORCE_DP=1 (parallel.collectives_on), so that the communicator is created with `device_id`, the construction-time
+    broadcast runs, every backward stage's slice of the flat gradient is all-reduced in place, asynchronously, on RCCL's
+    stream, `wait()` orders Adam behind it, and `global_loss` reduces a device tensor.  A one-rank sum is the identity and
+    1/world = 1, so gradients, parameters and losses must be BIT-equal to the plain single-process trainer's -- any wrong
+    stream ordering (an all-reduce that reads a slice before its stage has written it, an Adam that runs before the
+    exchange has landed) shows as a difference."""
+    import dp_worker as W
+    from xmm_superres_denoise.parallel import DataParallelTrainer
+    steps = 3
+    res = _launch(tmp_path, 1, "nccl", steps, math, kind, extra_env={"XSD_FORCE_DP": "1"})[0]
+    model = W.build(300, kind).cuda().set_math(math)
+    tr = DataParallelTrainer(model, lr=1e-3)
+    assert not tr.distributed
+    x, t = W.global_batch(kind)
+    x, t = x.cuda(), t.cuda()
+    for s in range(steps):
+        loss = float(tr.train_step(x, t))
+        assert np.array_equal(res["grads"][s], tr.grads.cpu().numpy()), s
+        assert np.array_equal(res["params"][s], tr.flat.cpu().numpy()), s
+        assert res["losses"][s] == loss
+    assert np.abs(res["params"][-1] - res["params"][0]).max() > 1e-4
+
+
+def test_bench_one_rank_over_rccl_with_the_reduce_path_forced():
+    """bench.py's own collective lines under RCCL on the one GPU (XSD_FORCE_DP=1): process group with device_id, barriers
+    around the timed region, the device-tensor all_reduce(MAX) of the step time, the all_gather of the replica hash."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", XSD_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "XSD_DIST_BACKEND"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--no-extra", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0, out[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["dist_backend"] == "nccl" and d["config"]["parallelism"] == "dp1"
+    assert d["replicas_identical"] is True and d["value"] > 0
+
+
+def test_train_driver_one_rank_over_rccl(tmp_path):
+    """train.py with a one-rank RCCL group (XSD_FORCE_DP=1): the trainer's exchange plus the validation epoch's state
+    reduction (EpochState.sync: device float64 tensors, SUM / MIN / MAX) over the nccl backend."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=os.path.join(root, "xmm-superres-denoise_amd"), XSD_FORCE_DP="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "XSD_DIST_BACKEND"):
+        env.pop(k, None)
+    ck = os.path.join(tmp_path, "one.ckpt")
+    cmd = [sys.executable, "-m", "xmm_superres_denoise.train", "fit", "--lr-res", "320", "--batch-size", "2", "--steps", "2", "--val-batches", "1",
+           "--loss", "paper", "--checkpoint", ck]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0, out[-3000:]
+    assert out.count("train/loss") == 2 and "validation:" in out and os.path.exists(ck)
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_bench_n_ranks_gloo_on_one_gpu(world):
     """`python bench.py --gpus N` as the driver launches it for N > 1 (self-launching here): N ranks, one process each, the
     DP train step with the staged all-reduce; over RCCL when N GPUs are visible, else the ranks share cuda:0 over gloo.
     The JSON line carries the whole-job value and the DDP invariant (bit-identical replicas after the timed steps).
-    (Four ranks: round 3 found gloo's own device all-reduce never returning with a power-of-two number of ranks on one GPU;
-    under gloo the gradient slices are reduced through a pinned host buffer since, parallel.py.)"""
+    (Four ranks: in round 3 gloo's device-tensor all-reduce stalled with three and more ranks on one GPU, cause undiagnosed;
+    under gloo the gradient slices are reduced through a pinned host buffer since -- copied on a side stream behind an event,
+    the host never blocks the enqueue of later stages: parallel.py.)"""
     import json
     root = os.path.dirname(HERE)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")

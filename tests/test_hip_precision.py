@@ -204,15 +204,23 @@ def _net_errors(size, blocks, seed, with_grad, batch=1, flip_aware=False, kind="
         dy = np.where(near, np.float32(0), dy)
 
     def torch_path(dtype, device):
+        # two tiles at a time: <dy, y> is a sum over tiles, so the parameter gradients accumulate over the chunks (autograd keeps
+        # ~20 GB of float64 activations per 512 x 512 tile)
         st = {k: v.to(device).requires_grad_(with_grad) for k, v in _state_t(state, dtype).items()}
-        xt = torch.from_numpy(x).to(dtype).to(device).requires_grad_(with_grad)
-        y = oracle.torch_forward(kind, 32, blocks, st, xt)
+        ys, dxs = [], []
+        for i in range(0, batch, 2):
+            xt = torch.from_numpy(x[i:i + 2]).to(dtype).to(device).requires_grad_(with_grad)
+            y = oracle.torch_forward(kind, 32, blocks, st, xt)
+            if with_grad:
+                y.backward(torch.from_numpy(dy[i:i + 2]).to(dtype).to(device))
+                dxs.append(xt.grad.cpu().numpy())
+            ys.append(y.detach().cpu().numpy())
+            del y, xt
         g = dx = None
         if with_grad:
-            y.backward(torch.from_numpy(dy).to(dtype).to(device))
             g = torch.cat([v.grad.reshape(-1) for v in st.values()]).cpu().numpy()
-            dx = xt.grad.cpu().numpy()
-        return y.detach().cpu().numpy(), g, dx
+            dx = np.concatenate(dxs)
+        return np.concatenate(ys), g, dx
 
     # the float64 yard-stick is evaluated by torch on the GPU (im2col + dgemm: seconds instead of minutes on the host cores; any
     # float64 evaluation is exact to ~1e-15 here); the fp32 yard-stick is torch's CPU path, the reference's own arithmetic
@@ -283,8 +291,10 @@ def test_full_size_forward_error_vs_float64():
 
 # (size, batch, seed, flip-aware per-tensor check): four seeds at 256 x 256, one at the BASELINE tile size with batch 2
 # (a second 512 x 512 seed, 7601, was measured once: profiles/r03_precision_first.log)
+# and (round 4) one at batch 8: 4096 tiles over the 256 persistent workgroups, i.e. every workgroup walks 16 tiles through several
+# batch slices, as at the bench batch of 32 -- every gradient tensor of every mode row-wise against float64 there too
 BACKWARD_CASES = [(256, 1, 7101, False), (256, 1, 7201, False), (256, 1, 7301, False), (256, 1, 7401, False),
-                  (512, 2, 7501, True)]
+                  (512, 2, 7501, True), (512, 8, 7701, True)]
 _BWD_RESULTS = {}
 
 

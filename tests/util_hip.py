@@ -15,10 +15,12 @@ def load_case(name, kind):
     nf, blocks, nup, wseed, xseed, tseed = [int(v) for v in z["meta"][:6]]
     xshape = tuple(int(v) for v in z["meta"][6:])
     lb = float(z["last_bias"][0])
-    state = gc.make_state(kind, nf, blocks, wseed, num_upsample=nup, last_bias=None if np.isnan(lb) else lb)
+    in_ch, out_ch = (int(v) for v in z["chan"]) if "chan" in z.files else (1, 1)     # image channel counts (round-4 width goldens)
+    assert in_ch == xshape[1]
+    state = gc.make_state(kind, nf, blocks, wseed, num_upsample=nup, last_bias=None if np.isnan(lb) else lb, in_ch=in_ch, out_ch=out_ch)
     x = gc.make_input(xshape, xseed)
     s = 2 ** nup if kind == "sr" else 1
-    t = gc.make_input((xshape[0], 1, xshape[2] * s, xshape[3] * s), tseed)
+    t = gc.make_input((xshape[0], out_ch, xshape[2] * s, xshape[3] * s), tseed)
     return z, nf, blocks, nup, state, x, t
 
 

@@ -22,7 +22,7 @@ y64 = oracle.torch_forward(kind, 32, 2, st64, x64, num_upsample=nup)
 torch.nn.functional.l1_loss(y64, torch.from_numpy(t).double()).backward()
 g64 = torch.cat([v.grad.reshape(-1) for v in st64.values()]).numpy()
 res = {"oracle": (yo, go, dxo)}
-for math in ("fp32", "bf16x6", "bf16x3"):
+for math in ("fp32", "bf16x6", "f16x3"):
     m = build_module(kind, 2, nup, state).set_math(math)
     eng = m._get_engine(torch.device("cuda", 0))
     eng.pack(m.flat_parameters())

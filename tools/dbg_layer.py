@@ -23,7 +23,7 @@ for (n_in, B, H, W, gscale) in [(1, 2, 64, 64, 1.0), (5, 1, 32, 64, 1.0), (3, 2,
     print(f"n_in={n_in} B={B} {H}x{W} gscale={gscale}: torch fp32 dx {rms(xt32.grad.numpy(), dx64):.2e} dw {rms(wt32.grad.numpy(), dw64):.2e}")
     xin = nchw_to_planes(x); gp = nchw_to_planes(g)[0]
     wd = torch.from_numpy(w).cuda()
-    for math in ("fp32", "bf16x6", "bf16x3"):
+    for math in ("fp32", "bf16x6", "f16x3"):
         e = Engine("dn", 1, 1, 32, 1); e.set_math(math)
         dxs = [torch.full((B, H, W, 32), float("nan"), device="cuda") for _ in range(n_in)]
         dw = torch.full_like(wd, float("nan")); db = torch.full((32,), float("nan"), device="cuda")

@@ -1,7 +1,7 @@
 # Round profiles on the GPU box: rocprofv3 kernel stats of the default bench line (f16x3) and of the strict / exact modes, PMC
 # traffic passes (separate --pmc runs, kernel-trace only), SQ counter passes of the f16x3 train step, plain bench lines of every
-# workload.  Everything lands in gpurun_out/prof_<tag>/ named for profiles/.  usage: bash tools/profile_round.sh r03
-R=$GRAFT_REPO_ROOT; TAG=${1:-r03}; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
+# workload.  Everything lands in gpurun_out/prof_<tag>/ named for profiles/.  usage: bash tools/profile_round.sh r04
+R=$GRAFT_REPO_ROOT; TAG=${1:-r04}; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for M in f16x3 bf16x6 fp32; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$M -- python3 $R/bench.py --math $M --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $O/${TAG}_dn_train_b32_${M}_bench_under_rocprof.json 2> $O/stats_$M.err || exit 1
@@ -15,6 +15,8 @@ PMC_BATCH=32 PMC_WORKLOAD=dn_train bash tools/pmc.sh f16x3 > $O/pmc_f16x3.log 2>
 python3 tools/pmc_read.py f16x3 > $O/${TAG}_pmc_sq_f16x3_dn_train_b32.txt || exit 1
 echo "sq counters done"
 python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_default.json 2> $O/bench_default.err || exit 1
+# the by-construction-fp32 mode as a first-class line of its own (headline slot, own cpu_baseline; its PMC traffic file is above)
+python3 bench.py --math bf16x6 --no-extra --steps 20 --warmup 5 > $O/${TAG}_bench_bf16x6.json 2> $O/bench_bf16x6.err || exit 1
 python3 bench.py --workload sr_fwd --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_sr_fwd.json 2>/dev/null || exit 1
 python3 bench.py --workload dn_fwd --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_dn_fwd.json 2>/dev/null || exit 1
 python3 bench.py --workload sr_train --steps 4 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_sr_train.json 2>/dev/null || exit 1

@@ -2,7 +2,7 @@ import sys, os, ctypes, torch
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, ROOT+'/xmm-superres-denoise_amd', ROOT+'/tests/golden'): sys.path.insert(0,p)
 from xmm_superres_denoise.models import GeneratorRRDB_DN
-math = sys.argv[1] if len(sys.argv)>1 else 'bf16x3'
+math = sys.argv[1] if len(sys.argv)>1 else 'f16x3'
 B = int(sys.argv[2]) if len(sys.argv)>2 else 8
 torch.manual_seed(0)
 m = GeneratorRRDB_DN(1,1,32,4).cuda().set_math(math)

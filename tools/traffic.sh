@@ -6,4 +6,4 @@ M=$1; B=${2:-32}
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/traffic_${M}_$C -- python3 $R/bench.py --steps 1 --warmup 1 --batch $B --no-cpu-baseline --no-profile --no-extra --math $M > $R/gpurun_out/traffic_${M}_$C.log 2>&1 || exit 1
 done
-python3 $R/tools/traffic_read.py $M $B ${3:-r03}
+python3 $R/tools/traffic_read.py $M $B ${3:-r04}

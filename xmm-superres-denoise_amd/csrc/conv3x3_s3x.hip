@@ -3,10 +3,11 @@
 // Reference layers: nn.Conv2d(32k -> 32, 3, 1, 1) of rrdb_blocks.py:27-31, generator_rrdb.py:38-44,95,101 (fp32) and
 // their autograd input-gradients.
 //
-// Arithmetic: as conv3x3_s3.hip (exact 3-term bf16 split of both operands, six bf16 MFMA products per fp32 product,
-// hi*hi in one accumulator and the five cross products in a second one, MFMA single-rounding accumulation).
+// Arithmetic: exact 3-term bf16 split of both operands (xsd_split.h: x = hi + mid + lo, each term the round-to-nearest bf16
+// of what the previous ones left), six bf16 MFMA products per fp32 product (hh, hm, mh, hl, lh, mm; dropped <= 2^-23
+// relative), hi*hi in one accumulator and the five cross products in a second one, MFMA single-rounding accumulation.
 //
-// Why roles.  In conv3x3_s3.hip every wave does everything, in order: a wave that is blocked issuing a global load or a
+// Why roles.  In a kernel whose waves all do everything in order (rounds 1-2 had one; git history) a wave that is blocked issuing a global load or a
 // store, or that runs its share of the fp32 -> 3 x bf16 conversion, issues no MFMA meanwhile.  Here the two kinds of work
 // live in different waves of the same SIMD, where the hardware overlaps them (MFMA and VALU/VMEM pipes are separate):
 //   * waves 0..3 (one per SIMD) stage: buffer_load the next-but-one input half-tile and weight half-panel as fp32 into
@@ -17,7 +18,13 @@
 //   * waves 4..11 (two per SIMD) multiply: tile rows 2w, 2w+1 of the 16 x 32 tile; their stream is ds_read_b128 + v_mfma
 //     (63 + 108 per half-step, fragments reused across the two rows), plus the epilogue at the end of a tile whose
 //     stores are dripped into the next half-step's walk.
-// Three waves per SIMD -> 168 registers per wave.  LDS images, swizzle, descriptors, trash page: conv3x3_s3.hip.
+// Three waves per SIMD -> 168 registers per wave.
+// LDS images: a staged half-tile is the 18 x 34 halo of 16 channels, stored once per term as [halo pixel][16 x bf16] = 32 B
+// per pixel in two 16-B slots (channels 0-7 | 8-15); slot s of halo column hx lies at ((s ^ ((hx >> 3) & 1)) << 4), so that
+// the 32 pixels x 2 halves a ds_read_b128 fragment request touches spread over all banks for every tap offset dx.  A weight
+// half-panel is [tap][term][64 lanes][8 x bf16] in MFMA fragment order (S3_WH_BYTES, xsd_kernels.h).  Global accesses are
+// raw-buffer accesses against per-plane descriptors (base = the plane's batch slice, range = its bytes): lanes outside the
+// image carry an offset that fails the range check and read zeros / store nothing.
 // What made it pay (each measured with the in-kernel stamps of the diagnostic build): no packed-f32
 // VALU beside the MFMAs (csrc/Makefile), an 22-instruction split, staging rounds without address arithmetic or
 // branches, LDS writes that are ds_write and not flat stores, counted waits instead of hipcc's vmcnt(0), deferred stores.

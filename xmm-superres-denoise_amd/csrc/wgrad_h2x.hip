@@ -91,7 +91,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
     const int l31 = lane & 31;
 #endif
 
-    // 1-D grid decode as in wgrad_s3.hip: the n_in workgroups that read the SAME G tiles have linear ids 8 apart -> one XCD
+    // 1-D grid decode (as in wgrad_s3x.hip): the n_in workgroups that read the SAME G tiles have linear ids 8 apart -> one XCD
     const int lin = blockIdx.x;
     const int xcd = lin & 7, qq = lin >> 3;
     const int j = qq % P.n_in;                        // input plane

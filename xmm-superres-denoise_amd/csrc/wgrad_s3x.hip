@@ -1,10 +1,14 @@
 // wgrad_s3x.hip -- math mode 3 ("bf16x6"): weight gradient of the 3x3 convs over fp32 planes, ROLE-SPLIT workgroup
-// (4 staging waves + 4 MFMA waves, one of each per SIMD, one workgroup per CU).  Arithmetic, LDS images, transposing
-// fragment reads, grid decode and the two-stage reduction are those of wgrad_s3.hip (see there); replaces autograd's conv
+// (4 staging waves + 4 MFMA waves, one of each per SIMD, one workgroup per CU).  Arithmetic: the exact 3-term bf16 split
+// of X and G (xsd_split.h), six products per multiply.  LDS images: per tile the X halo (6 x 34 pixels) and the G tile
+// (4 x 32), each as three term images [pixel][32 x bf16]; the GEMM's K index is the pixel, so fragments are read with the
+// transposing ds_read_b64_tr_b16 (pixels across lanes, four channels per lane).  Grid: 1-D, decoded so that the workgroups
+// which read the same G tiles share an XCD (below).  Partial sums per workgroup, then a fixed-order two-stage reduction
+// (wgrad_reduce_kernel, double accumulation): bitwise reproducible, no atomics.  Replaces autograd's conv
 // weight-gradient for the reference's nn.Conv2d(32k -> 32n, 3,1,1) layers (rrdb_blocks.py:27-31; generator_rrdb.py:38-44,95,101):
 //     dW[co][ci][tap] = sum_{b,y,x} G[b,y,x,co] * X[b,y+dy-1,x+dx-1,ci],   db[co] = sum G[..,co]
 //
-// Why roles.  In wgrad_s3.hip a wave stages (11 global loads, 11 splits, 33 LDS writes per 4-row tile) and multiplies (108
+// Why roles.  In the unified kernel of rounds 1-2 (git history) a wave stages (11 global loads, 11 splits, 33 LDS writes per 4-row tile) and multiplies (108
 // MFMAs) in turn; the stamps show it blocked ~3k cycles per tile just ISSUING its loads (8 waves x 11 KB in flight per CU
 // fill the vector-memory queue) and ~2.3k converting, against 3.5k of matrix time, and the co-resident second workgroup
 // only partly fills the holes.  Here
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
     const int h = lane >> 5;
     const int l31 = lane & 31;
 
-    // 1-D grid decode as in wgrad_s3.hip: the n_in workgroups that read the SAME G tiles have linear ids 8 apart -> one XCD
+    // 1-D grid decode: the n_in workgroups that read the SAME G tiles have linear ids 8 apart -> one XCD
     const int lin = blockIdx.x;
     const int xcd = lin & 7, qq = lin >> 3;
     const int j = qq % P.n_in;                        // input plane

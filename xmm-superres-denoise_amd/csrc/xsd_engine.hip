@@ -105,7 +105,8 @@ struct xsd_engine {
     // math mode 4 (f16x3): max |x| slots; [0] packed forward panels, [1] packed input-gradient panels, [2..] planes of the plan
     float* amax = nullptr;
     int amax_used = 2;
-    static constexpr int AMAX_CAP = 65536;
+    int amax_cap = 65536;      // floats allocated behind `amax`; ensure_plan grows it to what the plan's sizing pass counted (+ AMAX_TAIL)
+    static constexpr int AMAX_TAIL = 64;   // the last slots belong to the single-conv entry points (pack_single, the weight-gradient hook)
     const float* params = nullptr; // borrowed (bias reads)
     bool packed = false;
     // workspace
@@ -202,9 +203,11 @@ struct Builder {
 
     float* new_slot()
     {
-        if (e->amax_used >= xsd_engine::AMAX_CAP) return e->amax ? e->amax + xsd_engine::AMAX_CAP - 1 : nullptr;   // (never: ~10 slots per conv)
+        // one slot per plane view a launch writes or reads first.  The sizing pass of ensure_plan only COUNTS (a deep, wide net
+        // needs more than the initial allocation: 256 filters x 64 blocks is ~80k); the real pass runs after the array has
+        // been grown to the count, so no two planes ever share a slot
         const int i = e->amax_used++;
-        return e->amax ? e->amax + i : nullptr;
+        return (e->amax && i < e->amax_cap - xsd_engine::AMAX_TAIL) ? e->amax + i : nullptr;
     }
     void invalidate_range(uintptr_t lo, size_t bytes)
     {
@@ -955,6 +958,20 @@ static int ensure_plan(xsd_engine* e, int B, int H, int W, bool train)
         if (err != hipSuccess) return fail(XSD_ERR_NOMEM, "workspace hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(err));
         e->ws_bytes = need;
     }
+    if (e->amax_used + xsd_engine::AMAX_TAIL > e->amax_cap) {     // the sizing pass counted more max-|x| slots than are allocated
+        const int cap = ((e->amax_used + xsd_engine::AMAX_TAIL + 4095) / 4096) * 4096;
+        hipDeviceSynchronize();
+        float* grown = nullptr;
+        hipError_t err = hipMalloc((void**)&grown, sizeof(float) * (size_t)cap);
+        if (err == hipSuccess) err = hipMemset(grown, 0, sizeof(float) * (size_t)cap);
+        if (err != hipSuccess) { if (grown) hipFree(grown); return fail(XSD_ERR_NOMEM, "max-|x| slot array hipMalloc(%d floats) failed: %s", cap, hipGetErrorString(err)); }
+        if (e->amax) {      // slots 0 / 1 hold the packed panels' maxima (written by the last xsd_pack_weights): they move along
+            err = hipMemcpy(grown, e->amax, 2 * sizeof(float), hipMemcpyDeviceToDevice);
+            if (err != hipSuccess) { hipFree(grown); return fail(XSD_ERR_HIP, "max-|x| slot copy failed: %s", hipGetErrorString(err)); }
+            hipFree(e->amax);
+        }
+        e->amax = grown; e->amax_cap = cap;
+    }
     e->amax_used = 2;
     Builder real(e, B, H, W, train, reinterpret_cast<uintptr_t>(e->ws));
     real.build();
@@ -992,9 +1009,9 @@ extern "C" {
 
 const char* xsd_last_error(void) { return g_err.c_str(); }
 #ifdef XSD_DIAG
-const char* xsd_version(void) { return "xsd-hip gfx950 r3 (diagnostic variant)"; }
+const char* xsd_version(void) { return "xsd-hip gfx950 r4 (diagnostic variant)"; }
 #else
-const char* xsd_version(void) { return "xsd-hip gfx950 r3"; }
+const char* xsd_version(void) { return "xsd-hip gfx950 r4"; }
 #endif
 
 int xsd_create(const xsd_config* cfg, xsd_engine** out)
@@ -1098,8 +1115,8 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
         CK(hipMalloc((void**)&e->pad_descs, sizeof(PadDesc) * pads.size()));
         CK(hipMemcpy(e->pad_descs, pads.data(), sizeof(PadDesc) * pads.size(), hipMemcpyHostToDevice));
     }
-    CK(hipMalloc((void**)&e->amax, sizeof(float) * xsd_engine::AMAX_CAP));
-    CK(hipMemset(e->amax, 0, sizeof(float) * xsd_engine::AMAX_CAP));
+    CK(hipMalloc((void**)&e->amax, sizeof(float) * e->amax_cap));
+    CK(hipMemset(e->amax, 0, sizeof(float) * e->amax_cap));
     CK(hipMalloc((void**)&e->zero_page, 512));   // [0,256): zeros (padding source); [256,512): trash (stores of lanes outside the image)
     CK(hipMemset(e->zero_page, 0, 512));
     CK(hipMalloc((void**)&e->pk_edge, sizeof(float) * 2 * 288 * e->planes * (cfg->in_channels + cfg->out_channels)));   // [first_fwd | first_bwd][in channel][plane][288], [last_fwd | last_bwd][out channel][plane][288]
@@ -1136,7 +1153,8 @@ int xsd_set_math(xsd_engine* e, int mode)
     if (mode != e->math) { e->math = mode; e->packed = false; e->pB = 0; e->ptrain = -1; e->fwd_saved = false; }
     return XSD_OK;
 }
-int xsd_get_math(const xsd_engine* e) { return e ? e->math : -1; }
+// what the kernels actually compute in: the exact-fp32 kernels of generic_net.hip serve every mode setting
+int xsd_get_math(const xsd_engine* e) { return e ? (e->generic ? 0 : e->math) : -1; }
 
 int xsd_pack_weights(xsd_engine* e, const float* dev_params, void* stream)
 {
@@ -1457,7 +1475,7 @@ static hipError_t run_conv(xsd_engine* e, ConvParams& p, hipStream_t s)
     p.ablate = e->ablate;      // (0 outside the diagnostic library)
     for (int i = 0; i < (p.n_out > 1 ? p.n_out : p.n_in); ++i) p.wstep[i] = p.wpanel + (long long)i * PANEL_FLOATS;
     if (e->math == 4) {   // test hook: nobody has reported the operands' max |x| -> reduce them here (slots at the end of the array)
-        float* t = e->amax + xsd_engine::AMAX_CAP - 32;    // (CAP-16.. belong to the weight-gradient hook, CAP-4 / CAP-3 to pack_single)
+        float* t = e->amax + e->amax_cap - 32;    // (CAP-16.. belong to the weight-gradient hook, CAP-4 / CAP-3 to pack_single)
         hipError_t err = hipMemsetAsync(t, 0, 8 * sizeof(float), s);
         if (err != hipSuccess) return err;
         for (int i = 0; i < p.n_in; ++i) {
@@ -1479,12 +1497,12 @@ int xsd_test_conv3x3(xsd_engine* e, const float* const* in_planes, int n_in, con
     if (e->generic) return fail(XSD_ERR_ARG, "single-layer test hooks exist for the 32-filter MFMA path only");
     hipStream_t s = (hipStream_t)stream;
     float *fwd = nullptr, *bwd = nullptr;
-    int rc = pack_single(dev_w_oihw, 32 * n_out, 32 * n_in, &fwd, &bwd, e->math, s, e->amax + xsd_engine::AMAX_CAP - 4);
+    int rc = pack_single(dev_w_oihw, 32 * n_out, 32 * n_in, &fwd, &bwd, e->math, s, e->amax + e->amax_cap - 4);
     if (rc) return rc;
     Builder b(e, B, H, W, false, 0);
     ConvParams p = b.conv_base(0);
     p.n_in = n_in; p.n_out = n_out; p.wpanel = fwd; p.bias = dev_bias;
-    p.amax_w = e->amax + xsd_engine::AMAX_CAP - 4;     // mode 4: max |w| of the forward panels (pack_single)
+    p.amax_w = e->amax + e->amax_cap - 4;     // mode 4: max |w| of the forward panels (pack_single)
     for (int i = 0; i < n_in; ++i) p.in[i] = b.std_in(in_planes[i], 0);
     for (int j = 0; j < n_out; ++j) { b.std_out(p.out[j], out_planes[j], 0); p.out[j].slope = slope; }
     hipError_t err = run_conv(e, p, s);
@@ -1501,13 +1519,13 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
     if (e->generic) return fail(XSD_ERR_ARG, "single-layer test hooks exist for the 32-filter MFMA path only");
     hipStream_t s = (hipStream_t)stream;
     float *fwd = nullptr, *bwd = nullptr;
-    int rc = pack_single(dev_w_oihw, 32, 32 * n_in, &fwd, &bwd, e->math, s, e->amax + xsd_engine::AMAX_CAP - 4);
+    int rc = pack_single(dev_w_oihw, 32, 32 * n_in, &fwd, &bwd, e->math, s, e->amax + e->amax_cap - 4);
     if (rc) return rc;
     const float* g = dev_g_plane;
     Builder b(e, B, H, W, false, 0);
     ConvParams p = b.conv_base(0);
     p.n_in = 1; p.n_out = n_in; p.wpanel = bwd; p.in[0] = b.std_in(g, 0);
-    p.amax_w = e->amax + xsd_engine::AMAX_CAP - 3;     // mode 4: max |w| of the input-gradient panels
+    p.amax_w = e->amax + e->amax_cap - 3;     // mode 4: max |w| of the input-gradient panels
     for (int j = 0; j < n_in; ++j) b.std_out(p.out[j], dx_planes[j], 0);
     hipError_t err = run_conv(e, p, s);
     if (err == hipSuccess) {
@@ -1517,7 +1535,7 @@ int xsd_test_conv3x3_bwd(xsd_engine* e, const float* const* in_planes, int n_in,
         wp.g[0] = b.std_in(g, 0);
         wp.partial = e->wg_partial; wp.bias_partial = e->wg_bias_partial; wp.zero = e->zero_page; wp.ablate = e->ablate;
         if (e->math == 4) {   // test hook: reduce the operands' max |x| here (slots at the end of the array, after run_conv's)
-            float* t = e->amax + xsd_engine::AMAX_CAP - 16;
+            float* t = e->amax + e->amax_cap - 16;
             err = hipMemsetAsync(t, 0, 8 * sizeof(float), s);
             for (int i = 0; i < n_in && err == hipSuccess; ++i) { err = launch_plane_amax(wp.x[i], B, H, W, t + i, s); wp.amax_x[i] = t + i; }
             if (err == hipSuccess) { err = launch_plane_amax(wp.g[0], B, H, W, t + 5, s); wp.amax_g[0] = t + 5; }

@@ -47,7 +47,7 @@ constexpr int IN_LDS_BYTES = HALO_PX * 128;     // 43,520  (XOR-swizzled 16-B ch
 constexpr int PANEL_FLOATS = 9 * 32 * 32;       // 9,216 floats per (K-chunk x N-chunk) weight panel
 constexpr int W_LDS_BYTES = PANEL_FLOATS * 4;   // 36,864
 constexpr int CONV_LDS_BYTES = IN_LDS_BYTES + W_LDS_BYTES; // 80,384 -> 2 workgroups per CU (160 KiB LDS)
-// math mode 3 (bf16x6, conv3x3_s3.hip): a weight half-panel in LDS, split into three bf16 terms: [tap][hi|mid|lo][64 lanes][8 bf16]
+// math mode 3 (bf16x6, conv3x3_s3x.hip): a weight half-panel in LDS, split into three bf16 terms: [tap][hi|mid|lo][64 lanes][8 bf16]
 constexpr int S3_WH_BYTES = 9 * 3 * 1024;           // 27,648
 // math mode 4 (f16x3, conv3x3_h2x.hip): two fp16 terms: [tap][hi|lo][64 lanes][8 f16]
 constexpr int H2_WH_BYTES = 9 * 2 * 1024;           // 18,432
@@ -97,8 +97,7 @@ struct ConvParams {
                          // 4 skip the epilogue, 8 skip the MFMA loop; role-split kernel only: 16 two of three products,
                          // 32 idle sleep instead of the MFMA loop (with 8), 64 epilogue without its stores, 128 permuted
                          // fully coalesced stores, 256 fill LDS with realistic operand bits, 512 stores into an
-                         // L2-resident 64 KiB window per workgroup; conv3x3_p16: 16384 tap-major MFMA loop instead of the
-                         // row-reuse loop; wgrad_p16: 4096 G tile requested once per workgroup
+                         // L2-resident 64 KiB window per workgroup
     int pad_;
     const void* zero;    // 256 B of zeros + 256 B of trash in HBM (epilogue operand loads / stores of lanes outside the image)
     unsigned long long* dbg; // diagnostic phase stamps (null in production): [grid][8] accumulated shader cycles

@@ -1,4 +1,4 @@
-// xsd_split.h -- the exact 3-term bf16 split of math mode 3 ("bf16x6"), shared by conv3x3_s3*.hip and wgrad_s3.hip.
+// xsd_split.h -- the exact 3-term bf16 split of math mode 3 ("bf16x6"), shared by conv3x3_s3x.hip and wgrad_s3x.hip.
 // x = hi + mid + lo exactly (each term the round-to-nearest-even bf16 of what the previous terms left), four fp32 values
 // -> three word pairs of packed bf16.  Written over the natural pairs so that hipcc emits 22 VALU instructions per float4
 // (v_cvt_pk_bf16_f32, v_lshlrev/v_and to widen, v_sub_f32 for the residuals); the element-wise form it replaced compiled

@@ -17,7 +17,8 @@ def _mean_over_ranks(values: dict) -> dict:
     """`sync_dist=True` semantics of the reference's logging (models/model.py:118,150) for a metric collection that cannot
     reduce its own states: every rank contributes every key, in sorted order, so the collectives match."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not values:
+    from xmm_superres_denoise.parallel import collectives_on
+    if not collectives_on() or not values:
         return values
     keys = sorted(values)
     t = torch.stack([torch.as_tensor(values[k]).detach().double().reshape(()) for k in keys])

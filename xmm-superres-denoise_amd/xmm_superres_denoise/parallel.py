@@ -12,13 +12,26 @@ issued immediately on RCCL's stream while later stages compute.  The 1/world mea
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
 
+def collectives_on(group=None) -> bool:
+    """Does this process take the distributed code path?  Yes with more than one rank -- and with ONE rank when XSD_FORCE_DP=1:
+    a one-rank RCCL group on a single MI355X then executes every collective line a real node executes (communicator init
+    with `device_id`, the in-place asynchronous all-reduce of each gradient slice on RCCL's stream, `wait()`, the device-tensor
+    reductions of bench.py), with results that must be bit-equal to the plain single-process step (tests/test_hip_parallel.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("XSD_FORCE_DP", "0") == "1"
+
+
 def all_reduce_any(t: torch.Tensor, op=None, group=None) -> torch.Tensor:
-    """dist.all_reduce in place, wherever `t` lives: device tensors go through the host under gloo (whose own CUDA algorithms hung
-    with four ranks sharing one MI355X: DataParallelTrainer), stay on the device under RCCL."""
+    """dist.all_reduce in place, wherever `t` lives: device tensors go through the host under gloo (the rehearsal backend; its
+    device-tensor all-reduce stalled with three and more ranks sharing one MI355X, cause undiagnosed: DataParallelTrainer), stay
+    on the device under RCCL."""
     op = dist.ReduceOp.SUM if op is None else op
     if t.is_cuda and dist.get_backend(group) == "gloo":
         h = t.detach().cpu()
@@ -45,15 +58,19 @@ class DataParallelTrainer:
         self.step_count = 0
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        # gloo (the rehearsal backend for boxes with fewer GPUs than ranks) reduces device tensors with its own CUDA algorithms; with
-        # four ranks sharing ONE MI355X its power-of-two algorithm never returned (three ranks, ring, did).  Under gloo the gradient
-        # slices therefore travel through a pinned host buffer and are reduced as CPU tensors; RCCL ("nccl") reduces in place on
-        # the device, asynchronously, as before.
+        self.distributed = collectives_on(process_group)      # world > 1, or one rank with XSD_FORCE_DP=1 (the RCCL path on one GPU)
+        # gloo (the rehearsal backend for boxes with fewer GPUs than ranks): its device-tensor all-reduce was removed in round 3
+        # after multi-rank runs on ONE MI355X stalled -- three ranks took 5 s per batch-2 step (gpurun_out/dp3.log, ~60x too
+        # slow), four ranks did not come back inside the call's limit; the cause was never diagnosed (DESIGN.md section 7 has
+        # what is known).  Under gloo the gradient slices travel through a pinned host buffer and are reduced as CPU tensors;
+        # RCCL ("nccl") reduces in place on the device, asynchronously.
         self._host = None
-        if self.world > 1:
+        self._copy_stream = None
+        if self.distributed:
             # replicas must start identical (DDP broadcasts rank 0's parameters at construction)
             if dist.get_backend(process_group) == "gloo" and self.flat.is_cuda:
                 self._host = torch.empty(self.flat.numel(), dtype=torch.float32).pin_memory()
+                self._copy_stream = torch.cuda.Stream(device=self.flat.device)
                 self._host.copy_(self.flat)
                 dist.broadcast(self._host, src=0, group=process_group)
                 self.flat.copy_(self._host)
@@ -62,7 +79,7 @@ class DataParallelTrainer:
 
     def shard(self, global_batch: torch.Tensor) -> torch.Tensor:
         """This rank's contiguous slice of a global minibatch (DistributedSampler analogue, no shuffling)."""
-        rank = dist.get_rank(self.pg) if self.world > 1 else 0
+        rank = dist.get_rank(self.pg) if self.distributed else 0
         n = global_batch.shape[0]
         if n % self.world:
             raise ValueError(f"global batch {n} is not divisible by world size {self.world}")
@@ -79,18 +96,31 @@ class DataParallelTrainer:
         else:
             y = eng.forward(x, save_for_backward=True)
         loss, dy = eng.l1_loss(y, target) if self.loss is None else self.loss.value_and_grad(y, target)
-        works = []
+        works = []        # RCCL: (work, None) per stage
+        staged = []       # gloo: (copy-done event, offset, count) per stage
 
         def reduce_stage(st):
-            if self.world > 1:
-                off, cnt = eng.grad_range(st)
-                if self._host is None:
-                    works.append((dist.all_reduce(self.grads[off:off + cnt], op=dist.ReduceOp.SUM, group=self.pg, async_op=True), None))
-                else:       # gloo: device -> pinned host (after the stage's kernels), reduce on the host while later stages compute
-                    h = self._host[off:off + cnt]
-                    h.copy_(self.grads[off:off + cnt], non_blocking=True)
-                    torch.cuda.current_stream(self.grads.device).synchronize()
-                    works.append((dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), (off, cnt)))
+            if not self.distributed:
+                return
+            off, cnt = eng.grad_range(st)
+            if self._host is None:
+                # RCCL: in place on the device.  torch's NCCL process group makes its own stream wait for everything enqueued on
+                # the current stream so far (this stage's kernels) and returns at once; later stages run beside the exchange
+                works.append((dist.all_reduce(self.grads[off:off + cnt], op=dist.ReduceOp.SUM, group=self.pg, async_op=True), None))
+            else:
+                # gloo: device -> pinned host on a COPY stream that waits for an event recorded behind the stage's kernels.  The
+                # host does not block here (round 3 synchronised the compute stream at this point, which hid exactly the
+                # stage -> exchange ordering the RCCL branch relies on and serialised the rehearsal): later stages are enqueued
+                # at once, the host reductions start below as the copies land
+                cur = torch.cuda.current_stream(self.grads.device)
+                ready = torch.cuda.Event()
+                ready.record(cur)
+                with torch.cuda.stream(self._copy_stream):
+                    self._copy_stream.wait_event(ready)
+                    self._host[off:off + cnt].copy_(self.grads[off:off + cnt], non_blocking=True)
+                    landed = torch.cuda.Event()
+                    landed.record(self._copy_stream)
+                staged.append((landed, off, cnt))
 
         if recompute:
             backward_recompute(eng, x, dy, self.grads, False, me_chunk(), reduce_stage)
@@ -98,6 +128,9 @@ class DataParallelTrainer:
             for st in range(eng.num_stages):
                 eng.backward_stage(st, dy, self.grads)
                 reduce_stage(st)
+        for landed, off, cnt in staged:          # gloo: stage s is reduced on the host while the device still computes stages > s
+            landed.synchronize()
+            works.append((dist.all_reduce(self._host[off:off + cnt], op=dist.ReduceOp.SUM, group=self.pg, async_op=True), (off, cnt)))
         for w, back in works:
             w.wait()
             if back is not None:
@@ -110,7 +143,7 @@ class DataParallelTrainer:
 
     def global_loss(self, local_loss: torch.Tensor) -> torch.Tensor:
         """Mean of the per-rank mean losses (what `sync_dist=True` logging reports, models/model.py:118)."""
-        if self.world == 1:
+        if not self.distributed:
             return local_loss
         t = local_loss.detach().clone()
         all_reduce_any(t, dist.ReduceOp.SUM, self.pg)

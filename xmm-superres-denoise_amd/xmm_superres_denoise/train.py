@@ -58,7 +58,8 @@ def fit(name: str = "rrdb_denoise", lr_res: int = 416, batch_size: int = 4, step
                            "multi-rank path on fewer GPUs)")
     dev = torch.device(device or f"cuda:{local_rank if backend == 'nccl' else local_rank % ndev}")
     torch.cuda.set_device(dev)
-    if world > 1 and not dist.is_initialized():
+    force_dp = os.environ.get("XSD_FORCE_DP", "0") == "1"      # one rank, collectives on: the RCCL path on a single GPU (parallel.collectives_on)
+    if (world > 1 or force_dp) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)

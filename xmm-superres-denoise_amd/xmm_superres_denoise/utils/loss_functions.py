@@ -85,7 +85,8 @@ class EpochState:
         collective, with the identity state -- all zeros: the sums' identity, and the target range starts at [0, 0] on every
         rank anyway -- so the ranks' collective sequences always match.  If NO rank saw a batch the state stays empty."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        from xmm_superres_denoise.parallel import collectives_on
+        if not collectives_on(group):      # one rank (unless XSD_FORCE_DP=1 asks for the collectives anyway)
             return
         if self.acc is not None:
             a = self.acc.clone()
@@ -155,12 +156,21 @@ class Loss:
         _require_cuda_f32(target, "target")
         if preds.shape != target.shape:
             raise XsdError(f"shape mismatch {tuple(preds.shape)} vs {tuple(target.shape)}")
-        if preds.dim() == 4 and preds.shape[1] == 1:
-            B, _, H, W = preds.shape
+        if preds.dim() == 4:
+            # [B, C, H, W]: the kernels take one-channel images, so the channels fold into the batch (a contiguous NCHW tensor is
+            # B*C images).  That is exactly what torchmetrics computes for the element-wise terms (l1, poisson, mse -> psnr: means
+            # over all elements) and for ssim (per-image mean over C, H, W, then the mean over images: equal-sized groups).
+            # ms_ssim is the exception: torchmetrics averages each scale's contrast term over the CHANNELS of an image before the
+            # product over scales, which a per-channel product does not reproduce -- refused rather than approximated.
+            B, C, H, W = preds.shape
+            if C > 1 and self.weights.get("ms_ssim", 0.0) != 0.0:
+                raise XsdError(f"ms_ssim over {C}-channel images is not implemented (torchmetrics reduces an image's channels jointly per "
+                               "scale); use the l1 / poisson / psnr / ssim terms for multi-channel generators")
+            B = B * C
         elif preds.dim() == 3:
             B, H, W = preds.shape
         else:
-            raise XsdError(f"expected [B,1,H,W] or [B,H,W], got {tuple(preds.shape)}")
+            raise XsdError(f"expected [B,C,H,W] or [B,H,W], got {tuple(preds.shape)}")
         out = torch.empty(12, device=preds.device, dtype=torch.float32)
         dy = torch.empty_like(preds) if want_grad else None
         check(self.L.xsd_loss_eval(self.h, preds.data_ptr(), target.data_ptr(), dy.data_ptr() if want_grad else None,
