@@ -8,8 +8,13 @@
 // v_mfma_f32_16x16x32_f16 (four 16x16 tiles per 32x32 accumulator, K = the 32 pixels of a tile row).
 // The three products carry different weights, so they need their own accumulators: 27 32x32 accumulators (9 taps x {hh, hl, lh})
 // do not fit one wave.  The 27 single-MFMA "units" are dealt 4,4,4,3,3,3,3,3 to eight MFMA waves (7,7,7,6 per SIMD); each wave walks ALL rows of
-// the tile for its units (every wave reads a different subset of the fragments: the LDS read volume stays what it was), and the
-// weighted sum hh + 2^-11 (hl + lh), un-scaled exactly, is formed in the final fixed-order reduction.
+// the tile for its units, and the weighted sum hh + 2^-11 (hl + lh), un-scaled exactly, is formed in the final fixed-order reduction.
+// Round 4: the deal is by tap COLUMN.  A wave's three units are the taps (dy = 0, 1, 2; dx) of one product: at tile row r they
+// multiply the halo rows r, r+1, r+2 at column offset dx, so a row's X fragment is fetched ONCE and serves three steps from a
+// four-row register ring (one new fragment per step instead of three), and every wave needs only ONE term image of G.  Eight
+// of the nine (product, dx) triples go to the eight waves; the ninth (lh, dx = 2) is split over the three waves that hold four
+// units.  LDS fragment reads per tile row and CU: 144 -> 76 ds_read_b64_tr_b16 (the round-3 deal, units in tap order, gave
+// every unit its own fragment every step; the kernel's waves spent 26 % of their cycles stalled on LDS issue).
 // LDS: four images per buffer (X_h, X_l over the 10 x 34 halo, G_h, G_l), each [channel half][pixel][16 x f16]: 76,800 B, two buffers.
 #include <type_traits>
 #include "xsd_kernels.h"
@@ -25,9 +30,9 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef V3_SHAPE32      // -DV3_SHAPE32: the v_mfma_f32_32x32x16_f16 variant (A/B: this kernel 3.4 % FASTER per launch, the train step
-#define V3_SHAPE16 1    // 0.7 % SLOWER -- the chip is power-limited, the 16x16x32 shape draws less, and the conv launches between the
-#endif                  // weight-gradient launches run at a 2.5 % higher clock for it; two alternating pairs on one device)
+// (MFMA shape: v_mfma_f32_16x16x32_f16.  Round 2 A/B against the 32x32x16 form: this kernel 3.4 % slower per launch, the train
+// step 0.7 % FASTER -- the chip is power-limited, the 16x16x32 shape draws less, and the conv launches between the weight-gradient
+// launches run at a 2.5 % higher clock for it; the 32x32x16 variant left the tree in round 4, git history has it.)
 #ifndef V3_TH_ROWS
 #define V3_TH_ROWS 8     // 8-row tiles: halo 10/8 instead of 6/4 rows staged per row computed (4 rows: +6.7 % kernel time, one device)
 #endif
@@ -47,17 +52,13 @@ constexpr int V3_G_SLOTS = V3_TH * TILE_W * 8;                        // 2048
 constexpr int V3_G_ROUNDS = V3_G_SLOTS / V3_LT;                       // 8
 constexpr int V3_NL = V3_X_ROUNDS + V3_G_ROUNDS;                      // 19 loads per tile and staging thread
 constexpr int V3_XT = V3_HPX * 64;                                    // 21,760 B per X term image
-#ifdef V3_SHAPE16
-// v_mfma_f32_16x16x32_f16 variant: a term image is [channel half][pixel][16 x f16] (32-B records); the 32 lanes of a
+// A term image is [channel half][pixel][16 x f16] (32-B records); the 32 lanes of a
 // transposing read then take 256 contiguous bytes (8 pixels of one channel half): conflict-free at any pixel offset.  The
 // half-image strides are = 128 mod 256 so that a staging write (lanes 0-31: 4 pixels x both halves) is conflict-free too.
 constexpr int V3_XH = V3_HPX * 32;                                    // 10,880 B per X half image (= 128 mod 256)
 constexpr int V3_GH = V3_TH * TILE_W * 32 + 128;                      // 8,320 B per G half image
 constexpr int V3_GT = 2 * V3_GH;                                      // 16,640 B per G term image
 static_assert(V3_XH % 256 == 128 && V3_GH % 256 == 128 && 2 * V3_XH == V3_XT, "half-image strides");
-#else
-constexpr int V3_GT = V3_TH * TILE_W * 64;                            // 16,384 B per G term image
-#endif
 constexpr int V3_G_OFF = 2 * V3_XT;                                   // 43,520
 constexpr int V3_BUF = V3_G_OFF + 2 * V3_GT;                          // 76,288 B per buffer
 constexpr int V3_SINK = 2 * V3_BUF;                                   // writes of exhausted slots land behind the buffers (hi at +0, lo at +512)
@@ -66,17 +67,29 @@ constexpr int V3_LDS_BYTES = (V3_SINK + 1024) > V3_RED ? (V3_SINK + 1024) : V3_R
 static_assert(V3_LDS_BYTES <= 160 * 1024, "LDS");
 
 
-// 8 consecutive pixels (k = 8h + 0..7) of this lane's channel from a [pixel][32 x bf16] image
-__device__ __forceinline__ f16x8 v3_tr_frag(const char* lds_lane_base, int byte_off)
+// Which of the 27 accumulators ("units", u = 9 * product + tap; product 0 = Xh*Gh, 1 = Xh*Gl, 2 = Xl*Gh; tap = 3 dy + dx) MFMA wave w
+// holds in slot q: slots 0..2 = the column triple (product, dx) of the wave, taps dy = q; slot 3 (waves 0..2 only) = one tap of
+// the split triple (lh, dx = 2), dy = w.  Waves w and w + 4 share a SIMD: 7, 7, 7, 6 units per SIMD.
+__host__ __device__ constexpr int v3_triple_prod(int w) { return w < 3 ? 0 : (w < 6 ? 1 : 2); }
+__host__ __device__ constexpr int v3_triple_dx(int w) { return w < 3 ? w : (w < 6 ? w - 3 : w - 6); }
+__host__ __device__ constexpr int v3_unit(int w, int q)
 {
-    typedef __attribute__((address_space(3))) s16x4* lds_p;
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds_lane_base + byte_off));
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds_lane_base + byte_off + 4 * 64));
-    s16x8 r;
-    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
-    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
-    return __builtin_bit_cast(f16x8, r);
+    return q < 3 ? 9 * v3_triple_prod(w) + 3 * q + v3_triple_dx(w) : (w < 3 ? 18 + 3 * w + 2 : -1);
 }
+constexpr bool v3_deal_is_a_partition()
+{
+    bool seen[27] = {};
+    for (int w = 0; w < 8; ++w)
+        for (int q = 0; q < 4; ++q) {
+            const int u = v3_unit(w, q);
+            if (u < 0) continue;
+            if (u >= 27 || seen[u]) return false;
+            seen[u] = true;
+        }
+    for (int u = 0; u < 27; ++u) if (!seen[u]) return false;
+    return true;
+}
+static_assert(v3_deal_is_a_partition(), "every (product, tap) accumulator is held by exactly one wave");
 
 __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams P)
 {
@@ -86,10 +99,6 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wid < V3_LWAVES;   // wave-uniform role
-#ifndef V3_SHAPE16
-    const int h = lane >> 5;
-    const int l31 = lane & 31;
-#endif
 
     // 1-D grid decode (as in wgrad_s3x.hip): the n_in workgroups that read the SAME G tiles have linear ids 8 apart -> one XCD
     const int lin = blockIdx.x;
@@ -138,11 +147,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
     const float inv_s = inv_sx * inv_sg;
 
     constexpr int NU = 4;              // accumulators ("units") per MFMA wave: 27 = 4 + 4 + 4 + 3 + 3 + 3 + 3 + 3
-#ifdef V3_SHAPE16
     f32x4 acc[NU][2][2];               // [unit][input-channel half][output-channel half]: four 16x16 tiles per unit
-#else
-    f32x16 acc[NU];
-#endif
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f}; // staging thread: its 4 channels (lt & 7) of the G tiles it stages
 
     if (loader) {
@@ -171,12 +176,8 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             grel[r] = ((p >> 5) * gp.rs + (p & 31) * gp.ps + c * 4) * 4;
             ggx[r] = p & 31;
         }
-#ifdef V3_SHAPE16
         const int lds0 = (lt >> 3) * 32 + (lt & 3) * 8;        // + ((lt >> 2) & 1) * half-image stride (X and G differ) + r * V3_LT * 4
         const int xh0 = lds0 + ((lt >> 2) & 1) * V3_XH, gh0 = lds0 + ((lt >> 2) & 1) * V3_GH;
-#else
-        const int lds0 = lt * 8;
-#endif
         constexpr int RL = V3_X_ROUNDS - 1;                      // last X round: only part of the threads have a slot,
         const bool live6 = RL * V3_LT + lt < V3_X_SLOTS;         // the others write a sink
 
@@ -228,11 +229,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             if (abl & 1) { hi[0] = __float_as_uint(px[r][0]); hi[1] = __float_as_uint(px[r][1]); lo[0] = __float_as_uint(px[r][2]); lo[1] = __float_as_uint(px[r][3]); }
             else split2_f16x4(px[r], sx, hi, lo);
             const bool sink = (r == RL && !live6);
-            #ifdef V3_SHAPE16
             char* d = smem + (sink ? V3_SINK + (lt & 63) * 8 : buf + xh0 + r * (V3_LT * 4));
-#else
-            char* d = smem + (sink ? V3_SINK + (lt & 63) * 8 : buf + lds0 + r * (V3_LT * 8));
-#endif
             if (abl & 2) { asm volatile("" :: "v"(hi), "v"(lo), "v"(d)); return; }   // diag: no LDS writes
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + (sink ? 512 : V3_XT)) = lo;
@@ -241,11 +238,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             u32x2 hi, lo;
             if (abl & 1) { hi[0] = __float_as_uint(pg[r][0]); hi[1] = __float_as_uint(pg[r][1]); lo[0] = __float_as_uint(pg[r][2]); lo[1] = __float_as_uint(pg[r][3]); }
             else split2_f16x4(pg[r], sg, hi, lo);
-#ifdef V3_SHAPE16
             char* d = smem + buf + V3_G_OFF + gh0 + r * (V3_LT * 4);
-#else
-            char* d = smem + buf + V3_G_OFF + lds0 + r * (V3_LT * 8);
-#endif
             if (abl & 2) { asm volatile("" :: "v"(hi), "v"(lo), "v"(d)); bsum += pg[r]; return; }
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + V3_GT) = lo;
@@ -307,42 +300,37 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
 #ifdef V3_MPRIO
         __builtin_amdgcn_s_setprio(V3_MPRIO);
 #endif
-        const int wv = wid - V3_LWAVES;        // which of the 27 units (4,4,4,3,3,3,3,3 per wave); u / 9 = product (0 Xh*Gh, 1 Xh*Gl, 2 Xl*Gh), u % 9 = tap
+        const int wv = wid - V3_LWAVES;        // MFMA wave index: its units are v3_unit(wv, 0..3)
 #pragma unroll
         for (int k = 0; k < NU; ++k)
 #pragma unroll
-#ifdef V3_SHAPE16
             for (int i = 0; i < 16; ++i) acc[k][i >> 3][(i >> 2) & 1][i & 3] = 0.f;
-#else
-            for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
-#endif
         // per-lane base of the transposing reads: lane i of a 16-lane group addresses block row q = i>>2 (pixel) and
         // columns 4p..4p+3 (p = i&3) of channel group (lane>>4)&1; the lane half h selects pixels +8.
         const int i16 = lane & 15;
-#ifdef V3_SHAPE16
         // 16x16x32: lane group g = lane >> 4 supplies k = 8g .. 8g+7, which this kernel maps to the pixels 4g .. 4g+3 (first
         // read) and 16 + 4g .. 16 + 4g+3 (second read) of the 32-pixel row -- any k <-> pixel map serves, X and G use the same
         const int lane_off = (4 * (lane >> 4) + (i16 >> 2)) * 32 + (i16 & 3) * 8;
-#else
-        const int lane_off = (8 * h + (i16 >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (i16 & 3) * 8;
-#endif
         lds_barrier();                                                                     // (P)
         V3_TICK(1);
         // one instantiation per wave (the unit table is a compile-time function of the wave index)
         auto walk = [&](auto WV) {
             constexpr int w = decltype(WV)::value;
-            constexpr int u0 = w < 3 ? 4 * w : 12 + 3 * (w - 3), nu = w < 3 ? 4 : 3;   // waves w and w+4 share a SIMD: 7, 7, 7, 6 MFMAs per step
-            constexpr bool need_g1 = (u0 < 18 && u0 + nu > 9);              // some hl unit (u in 9..17)
-            constexpr bool need_g0x = (u0 < 9 || u0 + nu > 18);            // some hh or lh unit
+            constexpr int prodT = v3_triple_prod(w), dxT = v3_triple_dx(w);
+            constexpr bool single = w < 3;                                   // fourth unit: (lh, dy = w, dx = 2)
+            constexpr int x_img = prodT == 2 ? V3_XT : 0;                    // the triple's X term image: low term for lh
+            constexpr int g_img = prodT == 1 ? V3_GT : 0;                    // the wave's G term image: low term for hl (the single is lh: G high, like hh)
+            static_assert(!single || prodT == 0, "the waves with a fourth unit hold hh triples: one G image serves both");
 #pragma unroll 1
             for (int k = 0; k < my_tiles; ++k) {
-                const char* xb = smem + (k & 1) * V3_BUF + lane_off;                       // + term image + ((row+dy)*34 + dx + 16*mf) * 64
-                const char* gb = smem + (k & 1) * V3_BUF + V3_G_OFF + lane_off;            // + term image + (row*32 + 16*mf) * 64
-#ifdef V3_SHAPE16
-                // 16 steps (tile row r = st >> 1, input-channel half a = st & 1) of 32 pixels; per unit and step two MFMAs (the
-                // two output-channel halves).  The G fragments of a row are fetched with its a = 0 step and kept for a = 1;
-                // the fragments of step st+1 are requested before the MFMAs of step st
-                f16x8 xf[2][NU], gf[2][2][2];      // gf[row parity][term][output-channel half]
+                const char* xb = smem + (k & 1) * V3_BUF + lane_off;                       // + term image + half image + (halo row * 34 + dx) * 32
+                const char* gb = smem + (k & 1) * V3_BUF + V3_G_OFF + lane_off + g_img;    // + half image + row * 32 * 32
+                // 2 * V3_TH steps (tile row r = st >> 1, input-channel half a = st & 1) of 32 pixels; per unit and step two MFMAs (the
+                // two output-channel halves).  Halo row h's fragment of the wave's column lives in xr[h & 3][a] from the step
+                // that requests it (two rows ahead of its first use) until tile row h has used it as its dy = 0 operand; the G
+                // fragments of a row are fetched with its a = 0 step and kept for a = 1; the single unit's fragment is
+                // requested one step ahead.
+                f16x8 xr[4][2], xs[2], gf[2][2];      // gf[row parity][output-channel half]
                 auto frag16 = [&](const char* base, int off) {
                     typedef __attribute__((address_space(3))) s16x4* lds_p;
                     const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off));
@@ -352,62 +340,38 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
                     v[4] = hi4[0]; v[5] = hi4[1]; v[6] = hi4[2]; v[7] = hi4[3];
                     return __builtin_bit_cast(f16x8, v);
                 };
-                auto load_step = [&](int st, f16x8 (&x)[NU], f16x8 (&g)[2][2]) {
-                    const int r = st >> 1, a = st & 1;
-                    if (a == 0) {
+                auto load_row = [&](int hrow, int a) { xr[hrow & 3][a] = frag16(xb, x_img + a * V3_XH + (hrow * HALO_W + dxT) * 32); };
+                auto load_g = [&](int r) {
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            if (need_g0x) g[0][b] = frag16(gb, b * V3_GH + r * TILE_W * 32);
-                            if (need_g1) g[1][b] = frag16(gb, V3_GT + b * V3_GH + r * TILE_W * 32);
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < nu; ++q) {
-                        const int u = u0 + q, prod = u / 9, tap = u % 9, dy = tap / 3, dx = tap % 3;
-                        x[q] = frag16(xb, (prod == 2 ? V3_XT : 0) + a * V3_XH + ((r + dy) * HALO_W + dx) * 32);
-                    }
+                    for (int b = 0; b < 2; ++b) gf[r & 1][b] = frag16(gb, b * V3_GH + r * TILE_W * 32);
                 };
-                load_step(0, xf[0], gf[0]);
+                auto load_single = [&](int st) { xs[st & 1] = frag16(xb, V3_XT + (st & 1) * V3_XH + (((st >> 1) + w) * HALO_W + 2) * 32); };
+                // what step 0 and 1 need: halo rows 0, 1, 2 in both halves, G row 0, the single's first fragment
+                load_g(0);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) { load_row(0, a); load_row(1, a); load_row(2, a); }
+                if (single) load_single(0);
 #pragma unroll
                 for (int st = 0; st < 2 * V3_TH; ++st) {
-                    if (st + 1 < 2 * V3_TH) load_step(st + 1, xf[(st + 1) & 1], gf[((st + 1) >> 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);   // the requests go out BEFORE this step's MFMAs
+                    const int r = st >> 1, a = st & 1;
+                    // requests for later steps go out BEFORE this step's MFMAs: halo row r + 3 (first used by tile row r + 1; its
+                    // slot was last read by tile row r - 1), the next row's G with the a = 1 step, the single's next fragment
+                    if (r + 3 < V3_TH + 2) load_row(r + 3, a);
+                    if (a == 1 && r + 1 < V3_TH) load_g(r + 1);
+                    if (single && st + 1 < 2 * V3_TH) load_single(st + 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < nu; ++q) {
-                        const int prod = (u0 + q) / 9;
+                    for (int q = 0; q < 3; ++q)
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
-                            acc[q][st & 1][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[st & 1][q], gf[(st >> 1) & 1][prod == 1 ? 1 : 0][b], acc[q][st & 1][b], 0, 0, 0);
+                            acc[q][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xr[(r + q) & 3][a], gf[r & 1][b], acc[q][a][b], 0, 0, 0);
+                    if (single) {
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            acc[3][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xs[st & 1], gf[r & 1][b], acc[3][a][b], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#else
-                // 16 steps of 16 pixels (tile row r = st >> 1, pixel half mf = st & 1); the fragments of step st+1 are requested
-                // before the MFMAs of step st
-                f16x8 xf[2][NU], gf[2][2];
-                auto load_step = [&](int st, f16x8 (&x)[NU], f16x8 (&g)[2]) {
-                    const int r = st >> 1, mf = st & 1;
-                    if (need_g0x) g[0] = v3_tr_frag(gb, (r * TILE_W + 16 * mf) * 64);
-                    if (need_g1) g[1] = v3_tr_frag(gb, V3_GT + (r * TILE_W + 16 * mf) * 64);
-#pragma unroll
-                    for (int q = 0; q < nu; ++q) {
-                        const int u = u0 + q, prod = u / 9, tap = u % 9, dy = tap / 3, dx = tap % 3;
-                        x[q] = v3_tr_frag(xb, (prod == 2 ? V3_XT : 0) + ((r + dy) * HALO_W + dx + 16 * mf) * 64);
-                    }
-                };
-                load_step(0, xf[0], gf[0]);
-#pragma unroll
-                for (int st = 0; st < 2 * V3_TH; ++st) {
-                    if (st + 1 < 2 * V3_TH) load_step(st + 1, xf[(st + 1) & 1], gf[(st + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);   // the requests go out BEFORE this step's MFMAs
-#pragma unroll
-                    for (int q = 0; q < nu; ++q) {
-                        const int prod = (u0 + q) / 9;
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[st & 1][q], gf[st & 1][prod == 1 ? 1 : 0], acc[q], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#endif
                 V3_TICK(0);
                 lds_barrier();
                 V3_TICK(1);
@@ -435,22 +399,15 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
     float* outp = P.partial + ((((long long)part * P.n_g + n) * P.n_in + j) * 9) * 1024;
     if (!loader) {
         const int wv = wid - V3_LWAVES;
-        const int ub = wv < 3 ? 4 * wv : 12 + 3 * (wv - 3), un = wv < 3 ? 4 : 3;
 #pragma unroll
         for (int q = 0; q < NU; ++q) {
-            if (q < un) {
+            const int u = v3_unit(wv, q);            // slab = unit number 9 * product + tap (-1: this wave has no fourth unit)
+            if (u >= 0) {
 #pragma unroll
-#ifdef V3_SHAPE16
                 for (int i = 0; i < 16; ++i) {      // tile (a, b), register t: input channel 16a + 4 (lane >> 4) + t, output channel 16b + (lane & 15)
                     const int a = i >> 3, b = (i >> 2) & 1, t = i & 3;
-                    red[(ub + q) * 1024 + (16 * a + 4 * (lane >> 4) + t) * 32 + 16 * b + (lane & 15)] = acc[q][a][b][t];
+                    red[u * 1024 + (16 * a + 4 * (lane >> 4) + t) * 32 + 16 * b + (lane & 15)] = acc[q][a][b][t];
                 }
-#else
-                for (int i = 0; i < 16; ++i) {
-                    const int ci = (i & 3) + 8 * (i >> 2) + 4 * h;
-                    red[(ub + q) * 1024 + ci * 32 + l31] = acc[q][i];
-                }
-#endif
             }
         }
     }
