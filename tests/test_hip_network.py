@@ -35,6 +35,15 @@ TIGHT = {m: 2e-4 for m in MATHS}
 DX_TIGHT = {m: 4e-4 for m in MATHS}
 
 
+def _ripple_bar(x):
+    """What a flip candidate may do to the rows it does NOT name.  One LeakyReLU' decision that falls the other way changes one
+    (pixel, channel) term of the backward pass; every gradient upstream of it moves by about that term's share of the sum over
+    the pixels.  On the 1000+-pixel cases that ripple is far below north_star's 1e-3, which is the bar there; on the
+    9 x 11-pixel golden (sr_nf64_b1_up2: 99 pixels) one decision is 1 / 99 of everything -- measured 5e-3 on conv_first.weight --
+    so the bar is max(1e-3, 1 / pixels).  It applies only when the float64 evaluation names a candidate at all."""
+    return max(1e-3, 1.0 / float(x.shape[0] * x.shape[2] * x.shape[3]))
+
+
 def _report_flips(tag, before):
     recs = FLIP_LOG[before:]
     if recs:
@@ -54,8 +63,9 @@ def test_golden_forward_backward(name, kind, math):
     loss.backward()
     cand, n_out = flip_candidates(kind, blocks, state, x, t, nup) if math in FP32_CLASS else (None, 0)
     mark = len(FLIP_LOG)
+    strict = _ripple_bar(x)
     assert_grad_close(xd.grad.cpu().numpy().reshape(-1, x.shape[-1]), z["dx"].reshape(-1, x.shape[-1]), "dx", tight=DX_TIGHT[math], loose=5e-2, max_flip_frac=0.3,
-                      candidates=cand, n_out_candidates=n_out)
+                      candidates=cand, n_out_candidates=n_out, strict=strict)
     names = [str(n) for n in z["param_names"]]
     params = dict(m.named_parameters())
     assert list(params.keys()) == names
@@ -65,7 +75,7 @@ def test_golden_forward_backward(name, kind, math):
         assert abs(np.abs(g).sum() - a_ref) <= 1e-2 * a_ref + 1e-9, n
         assert abs(g.sum() - s_ref) <= 1e-2 * a_ref + 1e-9, n
         if "grad." + n in z.files:
-            assert_grad_close(g, z["grad." + n], n, tight=TIGHT[math], candidates=cand, n_out_candidates=n_out)
+            assert_grad_close(g, z["grad." + n], n, tight=TIGHT[math], candidates=cand, n_out_candidates=n_out, strict=strict)
     _report_flips(f"{name} {math}", mark)
 
 
@@ -441,9 +451,10 @@ def _widths_vs_float64(kind, nf, in_ch, out_ch, blocks, nup, shape, math=None):
     # may exceed 2e-4 of the tensor's largest entry; everything else must explain itself
     cand, n_out = flip_candidates(kind, blocks, state, x, t, nup)
     mark = len(FLIP_LOG)
-    assert_grad_close(xd.grad.cpu().numpy().reshape(-1, W), x64.grad.numpy().reshape(-1, W), "dx", tight=4e-4, loose=5e-2, candidates=cand, n_out_candidates=n_out)
+    strict = _ripple_bar(x)
+    assert_grad_close(xd.grad.cpu().numpy().reshape(-1, W), x64.grad.numpy().reshape(-1, W), "dx", tight=4e-4, loose=5e-2, candidates=cand, n_out_candidates=n_out, strict=strict)
     for n, p in m.named_parameters():
-        assert_grad_close(p.grad.cpu().numpy(), st64[n].grad.numpy(), n, tight=2e-4, loose=5e-2, candidates=cand, n_out_candidates=n_out)
+        assert_grad_close(p.grad.cpu().numpy(), st64[n].grad.numpy(), n, tight=2e-4, loose=5e-2, candidates=cand, n_out_candidates=n_out, strict=strict)
     _report_flips(f"{kind} nf={nf} {in_ch}->{out_ch} nup={nup} {math or 'default'}", mark)
     # and without autograd (no activations kept: two slabs ping-pong) the same output, bit for bit
     with torch.no_grad():

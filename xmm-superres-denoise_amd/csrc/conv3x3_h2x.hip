@@ -161,12 +161,12 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
         // wave in the scalar offset, the wave's 1-KiB destination in M0 -- written in the same statement, hipcc owns M0).
         // In the last round only waves 0 and 1 have slots; the other two land in the sink behind the buffer.
         const unsigned int lds0 = __builtin_amdgcn_readfirstlane((unsigned int)(unsigned long long)(__attribute__((address_space(3))) char*)smem);
-        auto dma_w_round = [&](int r, const i32x4& rs, int wb) {
+        auto dma_w_round = [&](int r, const i32x4& rs, int wb, bool on = true) {
             unsigned int all = ~0u;
             asm volatile("" : "+s"(all));
             const int voff = 16 * (int)__builtin_amdgcn_mbcnt_hi(all, __builtin_amdgcn_mbcnt_lo(all, 0u));
             const int soff = r * (X3_LT * 16) + wid * 1024;
-            const bool live = (r + 1) * X3_LT <= X3_WSLOTS || r * X3_LT + wid * 64 < X3_WSLOTS;     // wave-uniform
+            const bool live = on && ((r + 1) * X3_LT <= X3_WSLOTS || r * X3_LT + wid * 64 < X3_WSLOTS);     // wave-uniform
             const unsigned int dst = lds0 + L::WOFF + wb + (live ? soff : X3_WSINK + (wid & 1) * 1024);
             asm volatile("s_mov_b32 m0, %[l]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[o], %[r], %[s] offen lds"
                          :: [o] "v"(voff), [r] "s"(rs), [s] "s"(soff), [l] "s"(dst) : "memory");
@@ -280,10 +280,20 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
             // barrier retires them and leaves the input loads of half-step it+2 in flight; the pair waits below see
             // 8 - 2k older input loads + 5 pieces + 2k refills = 13 younger operations, as in the register scheme
             {
-                const i32x4 wrs1 = w_rsrc(n1, more1);
+#ifdef X3_WRES
+                // Launches with ONE weight panel (one input plane, one output chunk: conv1 of every dense block, the trunk conv and
+                // their input-gradient counterparts): the two half-panels of a tile are the two half-panels of every tile, and
+                // half-step `it` reads buffer it & 1 = its channel half -- so after the first two half-steps both buffers hold what
+                // every later half-step needs, and the pieces go out with an empty descriptor into the sink (same instruction
+                // stream, same counted waits, no traffic: 18 KB of the 58 KB a CU takes in per half-step)
+                const bool wlive = more1 && !(n_in * n_out == 1 && it >= 1);
+#else
+                const bool wlive = more1;
+#endif
+                const i32x4 wrs1 = w_rsrc(n1, wlive);
                 if (!(abl & 4)) {
 #pragma unroll
-                    for (int r = 0; r < X3_WR; ++r) dma_w_round(r, wrs1, wn);
+                    for (int r = 0; r < X3_WR; ++r) dma_w_round(r, wrs1, wn, wlive);
                 }
             }
             const i32x4 xrs = x_rsrc(n2, t2, more2);
