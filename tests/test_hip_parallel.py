@@ -143,9 +143,9 @@ def test_bench_n_ranks_gloo_on_one_gpu(world):
     """`python bench.py --gpus N` as the driver launches it for N > 1 (self-launching here): N ranks, one process each, the
     DP train step with the staged all-reduce; over RCCL when N GPUs are visible, else the ranks share cuda:0 over gloo.
     The JSON line carries the whole-job value and the DDP invariant (bit-identical replicas after the timed steps).
-    (Four ranks: in round 3 gloo's device-tensor all-reduce stalled with three and more ranks on one GPU, cause undiagnosed;
-    under gloo the gradient slices are reduced through a pinned host buffer since -- copied on a side stream behind an event,
-    the host never blocks the enqueue of later stages: parallel.py.)"""
+    (Four ranks: gloo's device-tensor all-reduce stalls behind device work when three or more processes share one GPU
+    (tools/gloo_cuda_probe.py, profiles/r04_gloo_cuda_probe.txt); under gloo the gradient slices are reduced through a pinned
+    host buffer -- copied on a side stream behind an event, the host never blocks the enqueue of later stages: parallel.py.)"""
     import json
     root = os.path.dirname(HERE)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -359,6 +359,18 @@ struct Builder {
         wp.B = B; wp.H = H << level; wp.W = W << level;
         wp.tilesX = (wp.W + TILE_W - 1) / TILE_W; wp.tilesY = (wp.H + TILE_H - 1) / TILE_H;
         wp.n_in = (int)xs.size(); wp.n_g = (int)gs.size(); wp.nparts = e->nparts;
+#ifndef XSD_WGRAD_ROUNDS
+        // The grid is nparts x n_in x n_g workgroups of one per CU: with nparts = the CU count a launch over k (X, G) pairs runs k
+        // rounds of workgroups, and every round pays a workgroup's fixed cost again (first two tiles' round trips, the final
+        // LDS reduction and partial-sum store, ~30 us of a ~450 us round: kernel trace, 0.476 / 0.911 / 1.359 / 1.731 / 2.250 ms
+        // for 1..5 pairs).  Where the pairs divide the CUs into a multiple of eight parts (2 and 4 pairs: 128 / 64 parts) the whole
+        // launch is ONE round of k-times longer workgroups; the workgroups that share G tiles still run side by side on one XCD.
+        // 3 and 5 pairs would leave 16 CUs idle (240 workgroups): they keep the k rounds.
+        {
+            const int pairs = wp.n_in * wp.n_g;
+            if (e->math >= 3 && pairs > 1 && e->nparts % pairs == 0 && ((e->nparts / pairs) & 7) == 0) wp.nparts = e->nparts / pairs;   // (the split modes' kernels: one workgroup per CU; the exact-fp32 kernel runs two)
+        }
+#endif
         for (size_t i = 0; i < xs.size(); ++i) wp.x[i] = xs[i];
         for (size_t i = 0; i < gs.size(); ++i) wp.g[i] = gs[i];
         std::vector<Launch> pre;     // math mode 4: reductions for planes nobody has reported yet

@@ -30,7 +30,7 @@ def collectives_on(group=None) -> bool:
 
 def all_reduce_any(t: torch.Tensor, op=None, group=None) -> torch.Tensor:
     """dist.all_reduce in place, wherever `t` lives: device tensors go through the host under gloo (the rehearsal backend; its
-    device-tensor all-reduce stalled with three and more ranks sharing one MI355X, cause undiagnosed: DataParallelTrainer), stay
+    device-tensor all-reduce stalls behind device work when three or more processes share one MI355X: DataParallelTrainer), stay
     on the device under RCCL."""
     op = dist.ReduceOp.SUM if op is None else op
     if t.is_cuda and dist.get_backend(group) == "gloo":
@@ -59,11 +59,13 @@ class DataParallelTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.distributed = collectives_on(process_group)      # world > 1, or one rank with XSD_FORCE_DP=1 (the RCCL path on one GPU)
-        # gloo (the rehearsal backend for boxes with fewer GPUs than ranks): its device-tensor all-reduce was removed in round 3
-        # after multi-rank runs on ONE MI355X stalled -- three ranks took 5 s per batch-2 step (gpurun_out/dp3.log, ~60x too
-        # slow), four ranks did not come back inside the call's limit; the cause was never diagnosed (DESIGN.md section 7 has
-        # what is known).  Under gloo the gradient slices travel through a pinned host buffer and are reduced as CPU tensors;
-        # RCCL ("nccl") reduces in place on the device, asynchronously.
+        # gloo (the rehearsal backend for boxes with fewer GPUs than ranks): its device-tensor all-reduce is not used.  With three
+        # ranks sharing ONE MI355X it took 5 s per batch-2 step (round 3, ~60x too slow), with four it did not come back.
+        # tools/gloo_cuda_probe.py reproduces that with no engine code at all -- asynchronous gloo all-reduces of device tensors
+        # behind plain torch matmuls: fine with two processes on the device, 0.6-2.9 s per iteration with three, no return with
+        # four (profiles/r04_gloo_cuda_probe.txt): gloo's CUDA path against the kernels of >= 3 processes time-slicing one device.
+        # It cannot occur with one process per GPU.  Under gloo the gradient slices therefore travel through a pinned host buffer
+        # and are reduced as CPU tensors; RCCL ("nccl") reduces in place on the device, asynchronously.
         self._host = None
         self._copy_stream = None
         if self.distributed:
