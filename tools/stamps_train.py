@@ -24,9 +24,9 @@ names = ['prologue', 'prefetch issue', 'MFMA loop', 'epilogue', 'wait+barrier1',
 tot = sum(v[:6])
 print(' conv: half-steps', v[6])
 for n, c in zip(names, v[:6]): print(f'  {n:52s} {c / max(v[6], 1):10.0f} cycles/item  {100 * c / max(tot, 1):5.1f}%')
-wn = ['staging rounds', 'MFMA walk', 'MFMA wave at the barrier', 'staging wave at the barrier']
+wn = ['staging rounds', 'MFMA walk', 'MFMA wave at the barrier', 'staging wave at the barrier', 'of the staging rounds: inside the counted data waits']
 print(' wgrad: tiles', v[21])
-for n, c in zip(wn, v[16:20]): print(f'  {n:52s} {c / max(v[21], 1):10.0f} cycles/tile')
+for n, c in zip(wn, v[16:21]): print(f'  {n:52s} {c / max(v[21], 1):10.0f} cycles/tile')
 if any(v[8:16]):
     print(' conv staging wave / youngest MFMA wave (cycles per half-step):')
     for n, c in zip(['input rounds', 'wait for DMA pieces', 'barrier', 'counted data waits', 'bookkeeping', 'youngest: MFMA loop', 'youngest: epilogue', 'youngest: barrier'], v[8:16]): print(f'  {n:52s} {c / max(v[6], 1):10.0f}')

@@ -52,6 +52,10 @@ constexpr int V3_G_SLOTS = V3_TH * TILE_W * 8;                        // 2048
 constexpr int V3_G_ROUNDS = V3_G_SLOTS / V3_LT;                       // 8
 constexpr int V3_NL = V3_X_ROUNDS + V3_G_ROUNDS;                      // 19 loads per tile and staging thread
 constexpr int V3_XT = V3_HPX * 64;                                    // 21,760 B per X term image
+#ifndef V3_SHAPE32
+#define V3_SHAPE16 1
+#endif
+#ifdef V3_SHAPE16
 // A term image is [channel half][pixel][16 x f16] (32-B records); the 32 lanes of a
 // transposing read then take 256 contiguous bytes (8 pixels of one channel half): conflict-free at any pixel offset.  The
 // half-image strides are = 128 mod 256 so that a staging write (lanes 0-31: 4 pixels x both halves) is conflict-free too.
@@ -59,6 +63,10 @@ constexpr int V3_XH = V3_HPX * 32;                                    // 10,880 
 constexpr int V3_GH = V3_TH * TILE_W * 32 + 128;                      // 8,320 B per G half image
 constexpr int V3_GT = 2 * V3_GH;                                      // 16,640 B per G term image
 static_assert(V3_XH % 256 == 128 && V3_GH % 256 == 128 && 2 * V3_XH == V3_XT, "half-image strides");
+#else
+// -DV3_SHAPE32 (v_mfma_f32_32x32x16_f16: K = 16 pixels, one MFMA per unit and step): a term image is [pixel][32 x f16] (64-B records)
+constexpr int V3_GT = V3_TH * TILE_W * 64;                            // 16,384 B per G term image
+#endif
 constexpr int V3_G_OFF = 2 * V3_XT;                                   // 43,520
 constexpr int V3_BUF = V3_G_OFF + 2 * V3_GT;                          // 76,288 B per buffer
 constexpr int V3_SINK = 2 * V3_BUF;                                   // writes of exhausted slots land behind the buffers (hi at +0, lo at +512)
@@ -99,6 +107,10 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wid < V3_LWAVES;   // wave-uniform role
+#ifndef V3_SHAPE16
+    const int h = lane >> 5;
+    const int l31 = lane & 31;
+#endif
 
     // 1-D grid decode (as in wgrad_s3x.hip): the n_in workgroups that read the SAME G tiles have linear ids 8 apart -> one XCD
     const int lin = blockIdx.x;
@@ -119,8 +131,10 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
     };
 
 #ifdef XSD_DIAG   // phase stamps (diagnostic library only; tools/stamps_train.py): slot 16 staging rounds, 17 MFMA walk, 18 MFMA
-                  // wave at the barrier, 19 staging wave at the barrier, 21 tiles (slots 0-15 belong to the conv kernels)
+                  // wave at the barrier, 19 staging wave at the barrier, 20 of [16]: inside the counted data waits, 21 tiles
+                  // (slots 0-15 belong to the conv kernels)
     unsigned long long st[2] = {0, 0};
+    unsigned long long wst = 0;
     unsigned long long t0 = __builtin_readcyclecounter();
     const bool stamp = P.dbg != nullptr;
 #define V3_TICK(i) do { if (stamp) { const unsigned long long t_ = __builtin_readcyclecounter(); st[i] += t_ - t0; t0 = t_; } } while (0)
@@ -147,7 +161,11 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
     const float inv_s = inv_sx * inv_sg;
 
     constexpr int NU = 4;              // accumulators ("units") per MFMA wave: 27 = 4 + 4 + 4 + 3 + 3 + 3 + 3 + 3
+#ifdef V3_SHAPE16
     f32x4 acc[NU][2][2];               // [unit][input-channel half][output-channel half]: four 16x16 tiles per unit
+#else
+    f32x16 acc[NU];
+#endif
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f}; // staging thread: its 4 channels (lt & 7) of the G tiles it stages
 
     if (loader) {
@@ -176,8 +194,12 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             grel[r] = ((p >> 5) * gp.rs + (p & 31) * gp.ps + c * 4) * 4;
             ggx[r] = p & 31;
         }
+#ifdef V3_SHAPE16
         const int lds0 = (lt >> 3) * 32 + (lt & 3) * 8;        // + ((lt >> 2) & 1) * half-image stride (X and G differ) + r * V3_LT * 4
         const int xh0 = lds0 + ((lt >> 2) & 1) * V3_XH, gh0 = lds0 + ((lt >> 2) & 1) * V3_GH;
+#else
+        const int lds0 = lt * 8;
+#endif
         constexpr int RL = V3_X_ROUNDS - 1;                      // last X round: only part of the threads have a slot,
         const bool live6 = RL * V3_LT + lt < V3_X_SLOTS;         // the others write a sink
 
@@ -229,7 +251,11 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             if (abl & 1) { hi[0] = __float_as_uint(px[r][0]); hi[1] = __float_as_uint(px[r][1]); lo[0] = __float_as_uint(px[r][2]); lo[1] = __float_as_uint(px[r][3]); }
             else split2_f16x4(px[r], sx, hi, lo);
             const bool sink = (r == RL && !live6);
+#ifdef V3_SHAPE16
             char* d = smem + (sink ? V3_SINK + (lt & 63) * 8 : buf + xh0 + r * (V3_LT * 4));
+#else
+            char* d = smem + (sink ? V3_SINK + (lt & 63) * 8 : buf + lds0 + r * (V3_LT * 8));
+#endif
             if (abl & 2) { asm volatile("" :: "v"(hi), "v"(lo), "v"(d)); return; }   // diag: no LDS writes
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + (sink ? 512 : V3_XT)) = lo;
@@ -238,7 +264,11 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             u32x2 hi, lo;
             if (abl & 1) { hi[0] = __float_as_uint(pg[r][0]); hi[1] = __float_as_uint(pg[r][1]); lo[0] = __float_as_uint(pg[r][2]); lo[1] = __float_as_uint(pg[r][3]); }
             else split2_f16x4(pg[r], sg, hi, lo);
+#ifdef V3_SHAPE16
             char* d = smem + buf + V3_G_OFF + gh0 + r * (V3_LT * 4);
+#else
+            char* d = smem + buf + V3_G_OFF + lds0 + r * (V3_LT * 8);
+#endif
             if (abl & 2) { asm volatile("" :: "v"(hi), "v"(lo), "v"(d)); bsum += pg[r]; return; }
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + V3_GT) = lo;
@@ -274,14 +304,26 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             const int nb = ((k + 1) & 1) * V3_BUF;
 #pragma unroll
             for (int r = 0; r < V3_X_ROUNDS; ++r) {
+#ifdef XSD_DIAG
+                const unsigned long long w0_ = __builtin_readcyclecounter();
+#endif
                 asm_wait(px[r]);
+#ifdef XSD_DIAG
+                wst += __builtin_readcyclecounter() - w0_;
+#endif
                 store_x(r, nb);
                 asm_load4(px[r], x_off(r, a), a.xrs);
                 __builtin_amdgcn_sched_barrier(0);   // one round at a time, in order (the wait counts depend on it)
             }
 #pragma unroll
             for (int r = 0; r < V3_G_ROUNDS; ++r) {
+#ifdef XSD_DIAG
+                const unsigned long long w1_ = __builtin_readcyclecounter();
+#endif
                 asm_wait(pg[r]);
+#ifdef XSD_DIAG
+                wst += __builtin_readcyclecounter() - w1_;
+#endif
                 store_g(r, nb);
                 asm_load4(pg[r], g_off(r, a), a.grs);
                 __builtin_amdgcn_sched_barrier(0);
@@ -292,7 +334,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef XSD_DIAG
-        if (stamp && tid == 0) { atomicAdd(&P.dbg[16], st[0]); atomicAdd(&P.dbg[19], st[1]); }
+        if (stamp && tid == 0) { atomicAdd(&P.dbg[16], st[0]); atomicAdd(&P.dbg[19], st[1]); atomicAdd(&P.dbg[20], wst); }
 #endif
         // tiles past the end were staged as zeros (empty descriptors): bsum took 0 from them; tile 0 and 1 were counted once each
     } else {
@@ -304,13 +346,21 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
 #pragma unroll
         for (int k = 0; k < NU; ++k)
 #pragma unroll
+#ifdef V3_SHAPE16
             for (int i = 0; i < 16; ++i) acc[k][i >> 3][(i >> 2) & 1][i & 3] = 0.f;
+#else
+            for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+#endif
         // per-lane base of the transposing reads: lane i of a 16-lane group addresses block row q = i>>2 (pixel) and
         // columns 4p..4p+3 (p = i&3) of channel group (lane>>4)&1; the lane half h selects pixels +8.
         const int i16 = lane & 15;
         // 16x16x32: lane group g = lane >> 4 supplies k = 8g .. 8g+7, which this kernel maps to the pixels 4g .. 4g+3 (first
         // read) and 16 + 4g .. 16 + 4g+3 (second read) of the 32-pixel row -- any k <-> pixel map serves, X and G use the same
+#ifdef V3_SHAPE16
         const int lane_off = (4 * (lane >> 4) + (i16 >> 2)) * 32 + (i16 & 3) * 8;
+#else
+        const int lane_off = (8 * h + (i16 >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (i16 & 3) * 8;
+#endif
         lds_barrier();                                                                     // (P)
         V3_TICK(1);
         // one instantiation per wave (the unit table is a compile-time function of the wave index)
@@ -325,6 +375,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             for (int k = 0; k < my_tiles; ++k) {
                 const char* xb = smem + (k & 1) * V3_BUF + lane_off;                       // + term image + half image + (halo row * 34 + dx) * 32
                 const char* gb = smem + (k & 1) * V3_BUF + V3_G_OFF + lane_off + g_img;    // + half image + row * 32 * 32
+#ifdef V3_SHAPE16
                 // 2 * V3_TH steps (tile row r = st >> 1, input-channel half a = st & 1) of 32 pixels; per unit and step two MFMAs (the
                 // two output-channel halves).  Halo row h's fragment of the wave's column lives in xr[h & 3][a] from the step
                 // that requests it (two rows ahead of its first use) until tile row h has used it as its dy = 0 operand; the G
@@ -372,6 +423,40 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#else
+                // -DV3_SHAPE32: 2 * V3_TH steps (tile row r = st >> 1, pixel half mf = st & 1) of 16 pixels, ONE 32x32x16 MFMA per unit and
+                // step; the same column ring (halo row h of the wave's column in xr[h & 3][mf]), G fragment per step
+                f16x8 xr[4][2], xs[2], gf[2];
+                auto frag32 = [&](const char* base, int off) {     // 8 consecutive pixels (k = 8h + 0..7) of this lane's channel from a [pixel][32 x f16] image
+                    typedef __attribute__((address_space(3))) s16x4* lds_p;
+                    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off));
+                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off + 4 * 64));
+                    s16x8 v;
+                    v[0] = lo4[0]; v[1] = lo4[1]; v[2] = lo4[2]; v[3] = lo4[3];
+                    v[4] = hi4[0]; v[5] = hi4[1]; v[6] = hi4[2]; v[7] = hi4[3];
+                    return __builtin_bit_cast(f16x8, v);
+                };
+                auto load_row = [&](int hrow, int mf) { xr[hrow & 3][mf] = frag32(xb, x_img + (hrow * HALO_W + dxT + 16 * mf) * 64); };
+                auto load_g = [&](int st) { gf[st & 1] = frag32(gb, ((st >> 1) * TILE_W + 16 * (st & 1)) * 64); };
+                auto load_single = [&](int st) { xs[st & 1] = frag32(xb, V3_XT + (((st >> 1) + w) * HALO_W + 2 + 16 * (st & 1)) * 64); };
+                load_g(0);
+#pragma unroll
+                for (int mf = 0; mf < 2; ++mf) { load_row(0, mf); load_row(1, mf); load_row(2, mf); }
+                if (single) load_single(0);
+#pragma unroll
+                for (int st = 0; st < 2 * V3_TH; ++st) {
+                    const int r = st >> 1, mf = st & 1;
+                    if (r + 3 < V3_TH + 2) load_row(r + 3, mf);
+                    if (st + 1 < 2 * V3_TH) load_g(st + 1);
+                    if (single && st + 1 < 2 * V3_TH) load_single(st + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xr[(r + q) & 3][mf], gf[st & 1], acc[q], 0, 0, 0);
+                    if (single) acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xs[st & 1], gf[st & 1], acc[3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
                 V3_TICK(0);
                 lds_barrier();
                 V3_TICK(1);
@@ -404,10 +489,17 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             const int u = v3_unit(wv, q);            // slab = unit number 9 * product + tap (-1: this wave has no fourth unit)
             if (u >= 0) {
 #pragma unroll
+#ifdef V3_SHAPE16
                 for (int i = 0; i < 16; ++i) {      // tile (a, b), register t: input channel 16a + 4 (lane >> 4) + t, output channel 16b + (lane & 15)
                     const int a = i >> 3, b = (i >> 2) & 1, t = i & 3;
                     red[u * 1024 + (16 * a + 4 * (lane >> 4) + t) * 32 + 16 * b + (lane & 15)] = acc[q][a][b][t];
                 }
+#else
+                for (int i = 0; i < 16; ++i) {
+                    const int ci = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    red[u * 1024 + ci * 32 + l31] = acc[q][i];
+                }
+#endif
             }
         }
     }
