@@ -51,7 +51,7 @@ def ptr_array(tensors):
     return arr
 
 
-def flip_candidates(kind, blocks, state, x, t, nup=1, eps=4e-6, return_clamp_mask=False):
+def flip_candidates(kind, blocks, state, x, t, nup=1, eps=4e-6, return_clamp_mask=False, device="cpu"):
     """Where can two fp32-accurate implementations legitimately take different branches of the network's step functions?
     A float64 evaluation of the reference graph (rrdb_blocks.py:37-54, generator_rrdb.py:66-137) records, for every conv
     that feeds a LeakyReLU, the output channels that hold a pre-activation within eps * rms(plane) of zero, plus whether any
@@ -62,7 +62,7 @@ def flip_candidates(kind, blocks, state, x, t, nup=1, eps=4e-6, return_clamp_mas
     [-1, W]): a decision that falls the other way at pixel (y, x) of a conv `depth` 3 x 3 convs behind the input changes dL/dx
     inside that pixel's receptive field, the image rows y - depth .. y + depth (low-resolution coordinates)."""
     import torch.nn.functional as F
-    st = {k: torch.from_numpy(v).double() for k, v in state.items()}
+    st = {k: torch.from_numpy(v).double().to(device) for k, v in state.items()}     # device="cuda": the float64 pass of a full-size batch takes seconds instead of minutes
     cand = {}
     B, C_in, H_in = x.shape[0], x.shape[1], x.shape[2]
     dx_rows = set()
@@ -88,7 +88,7 @@ def flip_candidates(kind, blocks, state, x, t, nup=1, eps=4e-6, return_clamp_mas
                         dx_rows.update(range((b * C_in + c) * H_in + lo, (b * C_in + c) * H_in + hi + 1))
         return F.leaky_relu(pre, slope)
 
-    xt = torch.from_numpy(x).double()
+    xt = torch.from_numpy(x).double().to(device)
     fea = conv("conv_first", xt)
     cur = fea
     for i in range(blocks):
@@ -109,11 +109,11 @@ def flip_candidates(kind, blocks, state, x, t, nup=1, eps=4e-6, return_clamp_mas
         out = conv("conv_last", fea) + xt
     if dx_rows:
         cand["__dx_rows__"] = dx_rows
-    tt = torch.from_numpy(t).double()
+    tt = torch.from_numpy(t).double().to(device)
     y = out.clamp(0, 1)
     n_out = int(((out.abs() < eps) | ((out - 1).abs() < eps) | ((y - tt).abs() < eps)).sum())
     if return_clamp_mask:      # output pixels whose PRE-clamp value is within 8 eps of a clamp bound (either side of it)
-        return cand, ((out.abs() < 8 * eps) | ((out - 1).abs() < 8 * eps)).numpy()
+        return cand, ((out.abs() < 8 * eps) | ((out - 1).abs() < 8 * eps)).cpu().numpy()
     return cand, n_out
 
 
