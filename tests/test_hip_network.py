@@ -48,7 +48,7 @@ def _report_flips(tag, before):
     recs = FLIP_LOG[before:]
     if recs:
         print(f"[flip report] {tag}: " + "; ".join(f"{r['tensor']}: {r['rows_over_tight']} rows over tight, {r['candidate_rows']} candidate rows, "
-                                                   f"{r['unexplained']} unexplained (max {r['max_rel_err']:.1e})" for r in recs))
+                                                   f"{r.get('ripple_rows', 0)} rippled from a downstream candidate, {r['unexplained']} unexplained (max {r['max_rel_err']:.1e})" for r in recs))
 
 
 @pytest.mark.parametrize("name,kind,math", [(n, k, m) for n, k in CASES + NF8_CASES + WIDTH_CASES for m in MATHS])

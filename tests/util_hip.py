@@ -120,6 +120,20 @@ def flip_candidates(kind, blocks, state, x, t, nup=1, eps=4e-6, return_clamp_mas
 FLIP_LOG = []     # one record per (case, tensor) that needed the flip allowance: printed by the tests, asserted to stay explainable
 
 
+def layer_order(prefix):
+    """position of a conv in the FORWARD pass (the state-dict order lists conv_last before the SR head)"""
+    if prefix == "conv_first":
+        return (0,)
+    if prefix.startswith("rrdb."):
+        _, i, r, c = prefix.split(".")
+        return (1, int(i), int(r[3:]), int(c[4:]))
+    if prefix == "trunk_conv":
+        return (2,)
+    if prefix.startswith("upsampling."):
+        return (3, int(prefix.split(".")[1]))
+    return (4,) if prefix == "HRconv" else (5,)
+
+
 def assert_grad_close(g, ref, name, tight=2e-4, loose=2e-2, max_flip_frac=0.15, candidates=None, n_out_candidates=0,
                       strict=1e-3):
     """Gradient comparison, relative to the tensor's largest entry.
@@ -127,10 +141,13 @@ def assert_grad_close(g, ref, name, tight=2e-4, loose=2e-2, max_flip_frac=0.15, 
     LeakyReLU', the clamp mask and sign(y - t) are step functions: an activation within ~1e-6 of zero can take a different
     branch in two fp32-accurate implementations.  That changes ONE (pixel, channel) term, i.e. the weight / bias gradient
     ROW of that output channel of that conv by O(1/sqrt(N)), and sends a ripple well below 1e-3 upstream.
-      * `candidates` given (flip-aware mode, used for the fp32-class math modes): only the rows named by
-        flip_candidates() for this tensor may exceed `tight` (up to `loose`); every other row must agree to `tight`, and
-        nothing anywhere may exceed north_star's 1e-3 (`strict`) unless it is a candidate row.  With no candidate for the
-        tensor (and no output-pixel candidate upstream of everything) ANY excess fails.
+      * `candidates` given (flip-aware mode, used for the fp32-class math modes): a row over `tight` must be EXPLAINED -- either
+        it is named by flip_candidates() for this tensor (that conv's output channel holds a pre-activation within rounding
+        of zero: up to `loose`), or a candidate sits DOWNSTREAM of this tensor in the forward pass (or at an output pixel):
+        the decision that falls the other way there changes one term of the backward pass and ripples into every gradient
+        upstream of it, far below north_star's 1e-3 (`strict`; the tests scale it for images of under 1000 pixels).  A
+        candidate upstream of the tensor explains nothing (the backward pass reaches this tensor first).  Rows that are
+        neither are counted as `unexplained` in FLIP_LOG and fail.
       * `candidates` None (16-bit tolerance-only modes): at most `max_flip_frac` of the rows may exceed `tight`, none
         `loose`, relative L2 error below `loose`/2."""
     g = np.asarray(g, np.float64).reshape(ref.shape)
@@ -146,14 +163,16 @@ def assert_grad_close(g, ref, name, tight=2e-4, loose=2e-2, max_flip_frac=0.15, 
         allowed = candidates.get(prefix, set()) if err.ndim >= 1 and name.rsplit(".", 1)[-1] in ("weight", "bias") else set()
         if name == "dx":       # rows of dL/dx inside the receptive field of a candidate pixel (flip_candidates)
             allowed = candidates.get("__dx_rows__", set())
-        unexplained = [int(b) for b in bad if int(b) not in allowed]
-        FLIP_LOG.append({"tensor": name, "rows_over_tight": len(bad), "candidate_rows": len(allowed), "unexplained": len(unexplained),
-                         "max_rel_err": float(err.max()), "output_candidates": n_out_candidates})
-        worst_unexplained = max([rows[b] for b in unexplained], default=0.0)
-        # a flip upstream of this tensor ripples into every row, far below north_star's 1e-3; an output-pixel candidate
-        # (clamp bound / L1 sign) does the same to every tensor
-        assert worst_unexplained <= (strict if (candidates or n_out_candidates) else tight), \
-            f"{name}: rows {unexplained[:8]} exceed {tight} (max {worst_unexplained:.3e}) without a flip candidate"
+        not_named = [int(b) for b in bad if int(b) not in allowed]
+        # a candidate DOWNSTREAM of this tensor (dL/dx: every layer is) or at an output pixel (clamp bound / L1 sign) ripples into it
+        here = (-1,) if name == "dx" else layer_order(prefix)
+        downstream = n_out_candidates > 0 or any(k != "__dx_rows__" and layer_order(k) > here for k in candidates)
+        ripple = [b for b in not_named if downstream and rows[b] <= strict]
+        unexplained = [b for b in not_named if b not in set(ripple)]
+        FLIP_LOG.append({"tensor": name, "rows_over_tight": len(bad), "candidate_rows": len(allowed), "ripple_rows": len(ripple),
+                         "unexplained": len(unexplained), "max_rel_err": float(err.max()), "output_candidates": n_out_candidates})
+        assert not unexplained, \
+            f"{name}: rows {unexplained[:8]} exceed {tight} (max {max(rows[b] for b in unexplained):.3e}) with no flip candidate on them or downstream of them"
         assert err.max() <= loose, f"{name}: max rel err {err.max():.3e} > loose {loose}"
         return
     nbad = len(bad)
