@@ -165,7 +165,16 @@ def main():
             out = os.path.join(d, "k.s")
             subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out] + extra, check=True, stderr=subprocess.DEVNULL)
             text = open(out).read()
-            n = check(text, nloads)
+            # one check per kernel of the file (conv3x3_h2x.hip holds the catch-all kernel and its per-kind instances): a kernel's
+            # text runs from its label to its s_endpgm / .Lfunc_end
+            funcs = re.split(r"(?m)^(?=\S+:\s*; @)", text)
+            funcs = [f for f in funcs if re.match(r"\S+:\s*; @", f) and "buffer_load_dwordx4" in f]
+            assert funcs, "no kernel with buffer loads in " + src
+            n = 0
+            for f in funcs:
+                n = check(f, nloads)
+            if len(funcs) > 1:
+                print("%s: %d kernels checked" % (src, len(funcs)))
             # no register spills: a scratch reload under these kernels' memory load is a ~4 us round trip, and the ones hipcc
             # once put into the conv epilogues and the accumulator initialisation cost 2-11 %
             spills = [l.strip() for l in text.splitlines() if l.strip().startswith("scratch_")]

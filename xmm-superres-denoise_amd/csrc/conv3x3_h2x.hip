@@ -58,7 +58,15 @@ constexpr int X3_WR = (X3_WSLOTS + X3_LT - 1) / X3_LT;     // 5 LDS-DMA pieces p
 
 __device__ __forceinline__ void x3_split4(const f32x4& a, float s, u32x2& hi, u32x2& lo) { split2_f16x4(a, s, hi, lo); }   // xsd_split.h
 
-__global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParams P)
+// Epilogue kind of a launch: bit 0 accumulate, 1 e1, 2 e2, 3 e3, 4 mask plane, 5 mask as compact bits, 6 compact-mask output (the
+// case labels of `epilogue` below).  KIND < 0: the catch-all instance that decides per output chunk at run time
+// (conv3x3_h2x_kernel); KIND >= 0: an instance that holds ONE epilogue variant and, for the kinds whose launches never have a
+// LeakyReLU of their own (operand and masked kinds: conv5, trunk, every input-gradient launch), no LeakyReLU instructions
+// either -- its own register allocation, chosen by the launcher when every output chunk of the launch is of that kind.
+constexpr bool x3_kind_has_lrelu(int kind) { return kind < 0 || kind == 0 || kind == 64; }
+
+template <int KIND>
+__device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef X3L L;
@@ -447,6 +455,11 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
 
     // Epilogue over fp32 planes (straight-line operand variants; lanes outside the image read the zero page and write a
     // trash page): each lane owns one pixel and 16 channels as four float4 groups.
+#ifdef X3_MBPREF
+    // (kind-48 instance only) the two compact-mask words of this lane, requested at the start of the tile's LAST half-step so that the
+    // round trip runs beside that half-step's MFMA walk instead of in the epilogue with the matrix pipe idle
+    unsigned int mb_pref[2] = {0u, 0u};
+#endif
     auto epilogue_v = [&](const OutDesc& o, const TileXY& T, auto has_acc, auto has_e1, auto has_e2, auto has_e3, auto has_mask, auto generic, auto has_bits, auto has_bout) {
         // has_bits: the lrelu' mask comes as one 16-bit word per lane and row (bits_in, written by the forward conv's epilogue
         // below: bit 4q + t <-> this lane's channel 8q + 4h + t) instead of the 128-byte-per-pixel activation plane
@@ -480,6 +493,10 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
             f32x4 va[4], v1[4], v2[4], v3[4], vm[4];
             const int widx = (((int)T.b * P.H + y) * P.W + x) * 2 + h;     // (pixel, lane half) -> 16-bit word (B*H*W*2 < 2^31)
             unsigned int mbits = 0, obits = 0;
+#ifdef X3_MBPREF
+            if constexpr (decltype(has_bits)::value && KIND == 48) mbits = mb_pref[r];
+            else
+#endif
             if constexpr (decltype(has_bits)::value) mbits = o.bits_in[valid ? widx : 0];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -499,8 +516,10 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
                 if constexpr (!fold_a2) v *= o.a2;
                 if constexpr (decltype(has_e2)::value) v += s2v * v2[q];
                 if constexpr (decltype(has_e3)::value) v += s3 * v3[q];
+                if constexpr (x3_kind_has_lrelu(KIND)) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = __builtin_fmaxf(v[t], v[t] * o.slope);   // = v > 0 ? v : v * slope for 0 <= slope <= 1 (0.2, 0.01, 1)
+                    for (int t = 0; t < 4; ++t) v[t] = __builtin_fmaxf(v[t], v[t] * o.slope);   // = v > 0 ? v : v * slope for 0 <= slope <= 1 (0.2, 0.01, 1)
+                }
                 if constexpr (decltype(has_bits)::value) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) v[t] = ((mbits >> (4 * q + t)) & 1u) ? v[t] : v[t] * msl;
@@ -530,15 +549,25 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
         using Y = std::true_type; using N = std::false_type;
         const int kind = (o.accumulate ? 1 : 0) | (o.e1 ? 2 : 0) | (o.e2 ? 4 : 0) | (o.e3 ? 8 : 0) | (o.mask ? 16 : 0);
         // (bits_out with operands other than none, bits_in without mask: not in the engine's plans -> rejected by the launcher)
-        switch (kind | ((o.mask && o.bits_in) ? 32 : 0) | (o.bits_out ? 64 : 0)) {
-        case 0: epilogue_v(o, T, N{}, N{}, N{}, N{}, N{}, N{}, N{}, N{}); break;
-        case 64: epilogue_v(o, T, N{}, N{}, N{}, N{}, N{}, N{}, N{}, Y{}); break;
-        case 2: epilogue_v(o, T, N{}, Y{}, N{}, N{}, N{}, N{}, N{}, N{}); break;
-        case 6: epilogue_v(o, T, N{}, Y{}, Y{}, N{}, N{}, N{}, N{}, N{}); break;
-        case 14: epilogue_v(o, T, N{}, Y{}, Y{}, Y{}, N{}, N{}, N{}, N{}); break;
-        case 16: epilogue_v(o, T, N{}, N{}, N{}, N{}, Y{}, N{}, N{}, N{}); break;
-        case 48: epilogue_v(o, T, N{}, N{}, N{}, N{}, Y{}, N{}, Y{}, N{}); break;
-        default: epilogue_v(o, T, Y{}, Y{}, Y{}, Y{}, Y{}, Y{}, N{}, N{}); break;   // any other combination (none in the engine's plans)
+        if constexpr (KIND == 0) epilogue_v(o, T, N{}, N{}, N{}, N{}, N{}, N{}, N{}, N{});
+        else if constexpr (KIND == 64) epilogue_v(o, T, N{}, N{}, N{}, N{}, N{}, N{}, N{}, Y{});
+        else if constexpr (KIND == 2) epilogue_v(o, T, N{}, Y{}, N{}, N{}, N{}, N{}, N{}, N{});
+        else if constexpr (KIND == 6) epilogue_v(o, T, N{}, Y{}, Y{}, N{}, N{}, N{}, N{}, N{});
+        else if constexpr (KIND == 14) epilogue_v(o, T, N{}, Y{}, Y{}, Y{}, N{}, N{}, N{}, N{});
+        else if constexpr (KIND == 16) epilogue_v(o, T, N{}, N{}, N{}, N{}, Y{}, N{}, N{}, N{});
+        else if constexpr (KIND == 48) epilogue_v(o, T, N{}, N{}, N{}, N{}, Y{}, N{}, Y{}, N{});
+        else {
+            static_assert(KIND < 0, "no epilogue variant for this kind");
+            switch (kind | ((o.mask && o.bits_in) ? 32 : 0) | (o.bits_out ? 64 : 0)) {
+            case 0: epilogue_v(o, T, N{}, N{}, N{}, N{}, N{}, N{}, N{}, N{}); break;
+            case 64: epilogue_v(o, T, N{}, N{}, N{}, N{}, N{}, N{}, N{}, Y{}); break;
+            case 2: epilogue_v(o, T, N{}, Y{}, N{}, N{}, N{}, N{}, N{}, N{}); break;
+            case 6: epilogue_v(o, T, N{}, Y{}, Y{}, N{}, N{}, N{}, N{}, N{}); break;
+            case 14: epilogue_v(o, T, N{}, Y{}, Y{}, Y{}, N{}, N{}, N{}, N{}); break;
+            case 16: epilogue_v(o, T, N{}, N{}, N{}, N{}, Y{}, N{}, N{}, N{}); break;
+            case 48: epilogue_v(o, T, N{}, N{}, N{}, N{}, Y{}, N{}, Y{}, N{}); break;
+            default: epilogue_v(o, T, Y{}, Y{}, Y{}, Y{}, Y{}, Y{}, N{}, N{}); break;   // any other combination (none in the engine's plans)
+            }
         }
         // every load of the epilogue (operands, register reloads) has landed before the MFMA walk starts: its deferred
         // stores then need no vector-memory waits (hipcc would otherwise put `vmcnt(1)` in front of each, i.e. wait for
@@ -567,6 +596,23 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
         const bool more1 = (it + 1 < items);
         X3_TICK(1);
         if (cur.i == 0 && cur.s2 == 0) init_acc(cur.j);
+#ifdef X3_MBPREF
+        if constexpr (KIND == 48) {
+            if (cur.i == n_in - 1 && cur.s2 == 1) {
+                const unsigned short* bin = P.out[cur.j].bits_in;
+                unsigned int all = ~0u;
+                asm volatile("" : "+s"(all));
+                const int ln = (int)__builtin_amdgcn_mbcnt_hi(all, __builtin_amdgcn_mbcnt_lo(all, 0u));
+                const int x = tcur.x0 + (ln & 31);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int y = tcur.y0 + wv * 2 + r;
+                    const bool valid = x < P.W && y < P.H;
+                    mb_pref[r] = bin[valid ? (((int)tcur.b * P.H + y) * P.W + x) * 2 + (ln >> 5) : 0];
+                }
+            }
+        }
+#endif
         compute(smem + xpar * X3_XB, it & 1, pending);
         xpar = (xpar + 1 == L::NXB) ? 0 : xpar + 1;
         pending = false;
@@ -622,14 +668,33 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParam
 #endif
 }
 
+__global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kernel(const ConvParams P) { conv3x3_h2x_body<-1>(P); }
+template <int KIND> __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_kind_kernel(const ConvParams P) { conv3x3_h2x_body<KIND>(P); }
+
+// Which kinds run on their own instance (bit i <-> X3_KIND_LIST[i]); the others, and every launch whose output chunks differ in
+// kind or carry a LeakyReLU an instance has dropped, run on the catch-all kernel.  Set from same-device per-kind measurements
+// (profiles/r04_ab_conv_kind_instances.txt): an instance is only worth its code if its launches get faster.
+#ifndef X3_KINDS
+#define X3_KINDS 68      // kinds 2 (one operand plane) and 48 (compact-mask read)
+#endif
+constexpr int X3_KIND_LIST[7] = {0, 64, 2, 6, 14, 16, 48};
+
 static PerDevice g_once;
+
+static int x3_kind_of(const OutDesc& o)
+{
+    return (o.accumulate ? 1 : 0) | (o.e1 ? 2 : 0) | (o.e2 ? 4 : 0) | (o.e3 ? 8 : 0) | (o.mask ? 16 : 0) | ((o.mask && o.bits_in) ? 32 : 0) | (o.bits_out ? 64 : 0);
+}
 
 hipError_t launch_conv3x3_h2x(const ConvParams& p, hipStream_t stream)
 {
     int ncu = 256;
     hipError_t e = g_once.once([]() {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2x_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, X3L::BYTES);
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X3L::BYTES);
+#define X3_ATTR(K) if (r == hipSuccess) r = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2x_kind_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, X3L::BYTES)
+        X3_ATTR(0); X3_ATTR(64); X3_ATTR(2); X3_ATTR(6); X3_ATTR(14); X3_ATTR(16); X3_ATTR(48);
+#undef X3_ATTR
+        return r;
     }, &ncu);
     if (e != hipSuccess) return e;
     if (p.n_in < 1 || p.n_out < 1 || p.n_in * p.n_out > 5 || !p.zero) return hipErrorInvalidValue;
@@ -651,7 +716,23 @@ hipError_t launch_conv3x3_h2x(const ConvParams& p, hipStream_t stream)
     const int ntiles = p.B * p.tilesX * tilesY;
     if (ntiles <= 0) return hipSuccess;
     const dim3 g(ntiles < ncu ? ntiles : ncu), b(X3_THREADS);
-    hipLaunchKernelGGL(conv3x3_h2x_kernel, g, b, X3L::BYTES, stream, p);
+    // the launch's kind: the same for every output chunk, and no LeakyReLU where the instance has none
+    int kind = x3_kind_of(p.out[0]);
+    for (int j = 1; j < p.n_out; ++j) if (x3_kind_of(p.out[j]) != kind) kind = -1;
+    if (kind >= 0 && !x3_kind_has_lrelu(kind))
+        for (int j = 0; j < p.n_out; ++j) if (p.out[j].slope != 1.f) kind = -1;
+    int idx = -1;
+    for (int i = 0; i < 7; ++i) if (X3_KIND_LIST[i] == kind && ((X3_KINDS >> i) & 1)) idx = i;
+    switch (idx) {
+    case 0: hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<0>, g, b, X3L::BYTES, stream, p); break;
+    case 1: hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<64>, g, b, X3L::BYTES, stream, p); break;
+    case 2: hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<2>, g, b, X3L::BYTES, stream, p); break;
+    case 3: hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<6>, g, b, X3L::BYTES, stream, p); break;
+    case 4: hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<14>, g, b, X3L::BYTES, stream, p); break;
+    case 5: hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<16>, g, b, X3L::BYTES, stream, p); break;
+    case 6: hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<48>, g, b, X3L::BYTES, stream, p); break;
+    default: hipLaunchKernelGGL(conv3x3_h2x_kernel, g, b, X3L::BYTES, stream, p); break;
+    }
     return hipGetLastError();
 }
 
