@@ -455,11 +455,6 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
 
     // Epilogue over fp32 planes (straight-line operand variants; lanes outside the image read the zero page and write a
     // trash page): each lane owns one pixel and 16 channels as four float4 groups.
-#ifdef X3_MBPREF
-    // (kind-48 instance only) the two compact-mask words of this lane, requested at the start of the tile's LAST half-step so that the
-    // round trip runs beside that half-step's MFMA walk instead of in the epilogue with the matrix pipe idle
-    unsigned int mb_pref[2] = {0u, 0u};
-#endif
     auto epilogue_v = [&](const OutDesc& o, const TileXY& T, auto has_acc, auto has_e1, auto has_e2, auto has_e3, auto has_mask, auto generic, auto has_bits, auto has_bout) {
         // has_bits: the lrelu' mask comes as one 16-bit word per lane and row (bits_in, written by the forward conv's epilogue
         // below: bit 4q + t <-> this lane's channel 8q + 4h + t) instead of the 128-byte-per-pixel activation plane
@@ -493,10 +488,6 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
             f32x4 va[4], v1[4], v2[4], v3[4], vm[4];
             const int widx = (((int)T.b * P.H + y) * P.W + x) * 2 + h;     // (pixel, lane half) -> 16-bit word (B*H*W*2 < 2^31)
             unsigned int mbits = 0, obits = 0;
-#ifdef X3_MBPREF
-            if constexpr (decltype(has_bits)::value && KIND == 48) mbits = mb_pref[r];
-            else
-#endif
             if constexpr (decltype(has_bits)::value) mbits = o.bits_in[valid ? widx : 0];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -596,23 +587,6 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
         const bool more1 = (it + 1 < items);
         X3_TICK(1);
         if (cur.i == 0 && cur.s2 == 0) init_acc(cur.j);
-#ifdef X3_MBPREF
-        if constexpr (KIND == 48) {
-            if (cur.i == n_in - 1 && cur.s2 == 1) {
-                const unsigned short* bin = P.out[cur.j].bits_in;
-                unsigned int all = ~0u;
-                asm volatile("" : "+s"(all));
-                const int ln = (int)__builtin_amdgcn_mbcnt_hi(all, __builtin_amdgcn_mbcnt_lo(all, 0u));
-                const int x = tcur.x0 + (ln & 31);
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int y = tcur.y0 + wv * 2 + r;
-                    const bool valid = x < P.W && y < P.H;
-                    mb_pref[r] = bin[valid ? (((int)tcur.b * P.H + y) * P.W + x) * 2 + (ln >> 5) : 0];
-                }
-            }
-        }
-#endif
         compute(smem + xpar * X3_XB, it & 1, pending);
         xpar = (xpar + 1 == L::NXB) ? 0 : xpar + 1;
         pending = false;
