@@ -488,9 +488,6 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
             f32x4 va[4], v1[4], v2[4], v3[4], vm[4];
             const int widx = (((int)T.b * P.H + y) * P.W + x) * 2 + h;     // (pixel, lane half) -> 16-bit word (B*H*W*2 < 2^31)
             unsigned int mbits = 0, obits = 0;
-#ifdef X3_EPI2
-            float row_max = 0.f;
-#endif
             if constexpr (decltype(has_bits)::value) mbits = o.bits_in[valid ? widx : 0];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -516,19 +513,7 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
                 }
                 if constexpr (decltype(has_bits)::value) {
 #pragma unroll
-#ifdef X3_EPI2
-                    for (int t = 0; t < 4; ++t) {      // bit -> all-ones / zero (v_bfe_i32), then a bitwise select (v_bfi_b32): three instructions per value instead of and / compare / multiply / select
-                        // (through asm: written in C, LLVM folds the pair back into and / compare / select)
-                        unsigned int sel;
-                        float r;
-                        const float b = v[t] * msl;
-                        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(mbits), "n"(4 * q + t));
-                        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(sel), "v"(v[t]), "v"(b));
-                        v[t] = r;
-                    }
-#else
                     for (int t = 0; t < 4; ++t) v[t] = ((mbits >> (4 * q + t)) & 1u) ? v[t] : v[t] * msl;
-#endif
                 } else if constexpr (decltype(has_mask)::value) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) v[t] = vm[q][t] > 0.f ? v[t] : v[t] * msl;
@@ -538,16 +523,9 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
                     for (int t = 0; t < 4; ++t) obits |= (v[t] > 0.f ? 1u : 0u) << (4 * q + t);
                 }
                 pend[4 * r + q] = v;
-#ifdef X3_EPI2
-#pragma unroll
-                for (int t = 0; t < 4; ++t) row_max = __builtin_fmaxf(row_max, __builtin_fabsf(v[t]));   // one select per ROW below (lanes outside the image hold finite values computed from zero inputs)
-            }
-            run_max = __builtin_fmaxf(run_max, valid ? row_max : 0.f);
-#else
 #pragma unroll
                 for (int t = 0; t < 4; ++t) run_max = __builtin_fmaxf(run_max, valid ? __builtin_fabsf(v[t]) : 0.f);   // select, no branch
             }
-#endif
             pend_off[r] = doff;
             if constexpr (decltype(has_bout)::value) { if (valid) o.bits_out[widx] = (unsigned short)obits; }
         }
