@@ -30,3 +30,7 @@ for n, c in zip(wn, v[16:21]): print(f'  {n:52s} {c / max(v[21], 1):10.0f} cycle
 if any(v[8:16]):
     print(' conv staging wave / youngest MFMA wave (cycles per half-step):')
     for n, c in zip(['input rounds', 'wait for DMA pieces', 'barrier', 'counted data waits', 'bookkeeping', 'youngest: MFMA loop', 'youngest: epilogue', 'youngest: barrier'], v[8:16]): print(f'  {n:52s} {c / max(v[6], 1):10.0f}')
+if any(v[22:27]):
+    ne = max(v[26], 1)
+    print(' conv epilogue split, oldest MFMA wave (cycles per epilogue, %d epilogues):' % v[26])
+    for n, c in zip(['entry -> first row operand / mask requests issued', 'first row arithmetic', 'second row (requests + arithmetic)', 'trailing vmcnt(0)'], v[22:26]): print(f'  {n:52s} {c / ne:10.0f}')

@@ -381,8 +381,27 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
         // prove it wave-uniform and wraps every store in a waterfall loop
         const unsigned long long d = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(pend_hi) << 32) |
                                      (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(pend_lo);   // (the builtin returns int: no sign extension)
+#ifdef X3_ASMSTORE
+        // The deferred stores go out through inline asm: hipcc's wait-count bookkeeping does not see them, so it puts no vmcnt wait
+        // in front of them -- and the epilogue no longer has to END with vmcnt(0) to keep those waits away, a wait that the stamps
+        // price at 1.4k cycles per epilogue on average (3-4k where the epilogue itself stores compact-mask words: it sat there
+        // until those two-byte stores were acknowledged).  What the stores need is that `pend` is not rewritten before they have
+        // read it: the epilogue STARTS with vmcnt(0), when every store in flight is at least a half-step old.
+        typedef int x3_i32x4 __attribute__((ext_vector_type(4)));
+        x3_i32x4 rsv;
+        rsv[0] = (int)(unsigned int)d; rsv[1] = (int)(unsigned int)((d >> 32) & 0xffffu);
+        rsv[2] = __builtin_amdgcn_readfirstlane(pend_nb); rsv[3] = 0x00020000;
+        const int off = pend_off[c >> 2];
+        switch (c & 3) {
+        case 0: asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(pend[c]), "v"(off), "s"(rsv)); break;
+        case 1: asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:32" :: "v"(pend[c]), "v"(off), "s"(rsv)); break;
+        case 2: asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:64" :: "v"(pend[c]), "v"(off), "s"(rsv)); break;
+        default: asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:96" :: "v"(pend[c]), "v"(off), "s"(rsv)); break;
+        }
+#else
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(d), 0, __builtin_amdgcn_readfirstlane(pend_nb), 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pend[c]), rs, pend_off[c >> 2] + 32 * (c & 3), 0, 0);
+#endif
     };
     auto compute = [&](const char* xc, int wpar, bool drip) {
         f16x8 xf[3][2], wf[3][2];   // [slot][term]: 0 = hi, 1 = lo (scaled 2^11)
@@ -455,6 +474,14 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
 
     // Epilogue over fp32 planes (straight-line operand variants; lanes outside the image read the zero page and write a
     // trash page): each lane owns one pixel and 16 channels as four float4 groups.
+#ifdef XSD_DIAG   // epilogue split (slots 22..26 of the stamp buffer, oldest MFMA wave): [22] entry -> first row's operand / mask requests issued,
+                  // [23] first row's arithmetic, [24] second row (requests + arithmetic), [25] the trailing vmcnt(0), [26] epilogues
+    unsigned long long est[5] = {0, 0, 0, 0, 0};
+    unsigned long long et0 = 0;
+#define X3_ETICK(i) do { if (P.dbg) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); est[i] += t_ - et0; et0 = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define X3_ETICK(i) do { } while (0)
+#endif
     auto epilogue_v = [&](const OutDesc& o, const TileXY& T, auto has_acc, auto has_e1, auto has_e2, auto has_e3, auto has_mask, auto generic, auto has_bits, auto has_bout) {
         // has_bits: the lrelu' mask comes as one 16-bit word per lane and row (bits_in, written by the forward conv's epilogue
         // below: bit 4q + t <-> this lane's channel 8q + 4h + t) instead of the 128-byte-per-pixel activation plane
@@ -497,6 +524,7 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
                 if constexpr (decltype(has_e3)::value) v3[q] = x3_gload4(p3 + 8 * q);
                 if constexpr (decltype(has_mask)::value && !decltype(has_bits)::value) vm[q] = x3_gload4(pm + 8 * q);
             }
+            if (r == 0) X3_ETICK(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 v;
@@ -528,6 +556,7 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
             }
             pend_off[r] = doff;
             if constexpr (decltype(has_bout)::value) { if (valid) o.bits_out[widx] = (unsigned short)obits; }
+            X3_ETICK(1 + r);
         }
         {
             const unsigned long long d = reinterpret_cast<unsigned long long>(dst);
@@ -536,6 +565,12 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
         }
     };
     auto epilogue = [&](int j, const TileXY& T) {
+#ifdef XSD_DIAG
+        if (P.dbg) { et0 = __builtin_readcyclecounter(); est[4] += 1; }
+#endif
+#ifdef X3_ASMSTORE
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the previous tile's deferred stores (a half-step old at least) have read `pend`
+#endif
         const OutDesc o = P.out[j];
         using Y = std::true_type; using N = std::false_type;
         const int kind = (o.accumulate ? 1 : 0) | (o.e1 ? 2 : 0) | (o.e2 ? 4 : 0) | (o.e3 ? 8 : 0) | (o.mask ? 16 : 0);
@@ -563,7 +598,10 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
         // every load of the epilogue (operands, register reloads) has landed before the MFMA walk starts: its deferred
         // stores then need no vector-memory waits (hipcc would otherwise put `vmcnt(1)` in front of each, i.e. wait for
         // the store before the previous one)
+#ifndef X3_ASMSTORE
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), gfx9 encoding
+#endif
+        X3_ETICK(3);
     };
 
 #ifdef XSD_DIAG   // phase stamps (diagnostic library variant only; tools/stamps.py): accumulated shader cycles per phase
@@ -634,6 +672,8 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
 #pragma unroll
         for (int q = 0; q < 6; ++q) atomicAdd(&P.dbg[q], st[q]);
         atomicAdd(&P.dbg[6], (unsigned long long)items);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) atomicAdd(&P.dbg[22 + q], est[q]);
         atomicAdd(&P.dbg[7], __builtin_amdgcn_s_memrealtime() - rt0);
     }
     if (stamp && tid == 64 * (X3_LWAVES + X3_MWAVES - 1)) {   // the youngest MFMA wave: slots 13..15 = MFMA walk, epilogue, barrier A
