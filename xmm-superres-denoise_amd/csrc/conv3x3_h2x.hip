@@ -381,27 +381,8 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
         // prove it wave-uniform and wraps every store in a waterfall loop
         const unsigned long long d = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(pend_hi) << 32) |
                                      (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(pend_lo);   // (the builtin returns int: no sign extension)
-#ifdef X3_ASMSTORE
-        // The deferred stores go out through inline asm: hipcc's wait-count bookkeeping does not see them, so it puts no vmcnt wait
-        // in front of them -- and the epilogue no longer has to END with vmcnt(0) to keep those waits away, a wait that the stamps
-        // price at 1.4k cycles per epilogue on average (3-4k where the epilogue itself stores compact-mask words: it sat there
-        // until those two-byte stores were acknowledged).  What the stores need is that `pend` is not rewritten before they have
-        // read it: the epilogue STARTS with vmcnt(0), when every store in flight is at least a half-step old.
-        typedef int x3_i32x4 __attribute__((ext_vector_type(4)));
-        x3_i32x4 rsv;
-        rsv[0] = (int)(unsigned int)d; rsv[1] = (int)(unsigned int)((d >> 32) & 0xffffu);
-        rsv[2] = __builtin_amdgcn_readfirstlane(pend_nb); rsv[3] = 0x00020000;
-        const int off = pend_off[c >> 2];
-        switch (c & 3) {
-        case 0: asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(pend[c]), "v"(off), "s"(rsv)); break;
-        case 1: asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:32" :: "v"(pend[c]), "v"(off), "s"(rsv)); break;
-        case 2: asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:64" :: "v"(pend[c]), "v"(off), "s"(rsv)); break;
-        default: asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:96" :: "v"(pend[c]), "v"(off), "s"(rsv)); break;
-        }
-#else
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(d), 0, __builtin_amdgcn_readfirstlane(pend_nb), 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pend[c]), rs, pend_off[c >> 2] + 32 * (c & 3), 0, 0);
-#endif
     };
     auto compute = [&](const char* xc, int wpar, bool drip) {
         f16x8 xf[3][2], wf[3][2];   // [slot][term]: 0 = hi, 1 = lo (scaled 2^11)
@@ -568,9 +549,6 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
 #ifdef XSD_DIAG
         if (P.dbg) { et0 = __builtin_readcyclecounter(); est[4] += 1; }
 #endif
-#ifdef X3_ASMSTORE
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the previous tile's deferred stores (a half-step old at least) have read `pend`
-#endif
         const OutDesc o = P.out[j];
         using Y = std::true_type; using N = std::false_type;
         const int kind = (o.accumulate ? 1 : 0) | (o.e1 ? 2 : 0) | (o.e2 ? 4 : 0) | (o.e3 ? 8 : 0) | (o.mask ? 16 : 0);
@@ -598,9 +576,7 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
         // every load of the epilogue (operands, register reloads) has landed before the MFMA walk starts: its deferred
         // stores then need no vector-memory waits (hipcc would otherwise put `vmcnt(1)` in front of each, i.e. wait for
         // the store before the previous one)
-#ifndef X3_ASMSTORE
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), gfx9 encoding
-#endif
         X3_ETICK(3);
     };
 
