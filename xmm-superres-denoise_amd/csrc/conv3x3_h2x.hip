@@ -64,12 +64,6 @@ __device__ __forceinline__ void x3_split4(const f32x4& a, float s, u32x2& hi, u3
 // LeakyReLU of their own (operand and masked kinds: conv5, trunk, every input-gradient launch), no LeakyReLU instructions
 // either -- its own register allocation, chosen by the launcher when every output chunk of the launch is of that kind.
 constexpr bool x3_kind_has_lrelu(int kind) { return kind < 0 || kind == 0 || kind == 64; }
-// Input-fragment slots of the MFMA walk: three (requests two steps ahead) in the catch-all kernel and the instances that sit at the
-// register cap; X3_XDEPTH (experiment: 4 = three steps ahead, eight more registers) in the instances that have the room.
-#ifndef X3_XDEPTH
-#define X3_XDEPTH 3
-#endif
-constexpr int x3_xslots(int kind) { return (kind == 0 || kind == 2 || kind == 6 || kind == 14 || kind == 16) ? X3_XDEPTH : 3; }
 
 template <int KIND>
 __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
@@ -391,8 +385,7 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pend[c]), rs, pend_off[c >> 2] + 32 * (c & 3), 0, 0);
     };
     auto compute = [&](const char* xc, int wpar, bool drip) {
-        constexpr int NX = x3_xslots(KIND);
-        f16x8 xf[NX][2], wf[3][2];   // [slot][term]: 0 = hi, 1 = lo (scaled 2^11)
+        f16x8 xf[3][2], wf[3][2];   // [slot][term]: 0 = hi, 1 = lo (scaled 2^11)
         // fragment base offsets rebuilt per half-step from the lane id (a few VALU): held across the loop they get spilled,
         // and a scratch reload in front of the MFMAs is a vector-memory round trip
         int abase[3];
@@ -444,21 +437,17 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
         load_w(0, wf[0]);
         load_x(1, 0, xf[1]);
         load_w(1 * 3 + 0, wf[1]);
-        if constexpr (NX > 3) load_x(2, 0, xf[2]);
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
             const int dx = s >> 2, ir = s & 3;
-            if (s + NX - 1 < 12) {
-                const int sx = s + NX - 1;
-                load_x(sx & 3, sx >> 2, xf[sx % NX]);
-            }
             if (s + 2 < 12) {
                 const int dx2 = (s + 2) >> 2, ir2 = (s + 2) & 3;
+                load_x(ir2, dx2, xf[(s + 2) % 3]);
                 if (ir2 <= 2) load_w(ir2 * 3 + dx2, wf[(3 * dx2 + ir2) % 3]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (ir >= 1) mac(1, wf[(3 * dx + ir - 1) % 3], xf[s % NX]);      // output row 1, tap (dy = ir - 1, dx)
-            if (ir <= 2) mac(0, wf[(3 * dx + ir) % 3], xf[s % NX]);          // output row 0, tap (dy = ir, dx)
+            if (ir >= 1) mac(1, wf[(3 * dx + ir - 1) % 3], xf[s % 3]);      // output row 1, tap (dy = ir - 1, dx)
+            if (ir <= 2) mac(0, wf[(3 * dx + ir) % 3], xf[s % 3]);          // output row 0, tap (dy = ir, dx)
             if (drip && s >= 1 && s <= 8) store_pending(s - 1);
             __builtin_amdgcn_sched_barrier(0);
         }
