@@ -128,7 +128,8 @@ MATHS = {
                "single-rounding f32 accumulate, f32 planes)", "conv3x3_s3x_kernel"),
     "f16x3": ("f16x3 (f32 planes and f32 accumulate; operands as 2-term fp16 splits of power-of-two-scaled tensors = 22-23 significant "
               "bits per operand, 3 fp16 MFMA products per multiply; gradients measured at 1.2-1.6x the float64-error of torch's fp32 path)",
-              "conv3x3_h2x_kernel"),
+              "conv3x3_h2x_kernel + its per-epilogue-kind instances conv3x3_h2x_kind_kernel<2>, <48> (one kernel body; rocprofv3 lists three names: the "
+              "average launch time here is over all of them)"),
 }
 DEFAULT_MATH = "f16x3"
 MATH_PRODUCTS = {"bf16x6": 6, "f16x3": 3}   # 16-bit MFMAs per fp32 product
