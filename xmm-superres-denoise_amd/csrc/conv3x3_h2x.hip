@@ -150,6 +150,15 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
         if constexpr (KIND >= 0) {
             float* sct = reinterpret_cast<float*>(smem + L::SCALE);
             float sum_amax = 0.f;
+            // the smallest scale among the launch's split planes: the fp32 planes (converted on the fly, any scale that cannot
+            // overflow will do) adopt it when it is within 2^8 of their own, so that most K-loops run on ONE scale and the
+            // accumulators are never rescaled
+            float s_split = 0.f;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const float* sp = P.in[i].scale;
+                if (i < n_in && sp) { const float v = *sp; s_split = (s_split == 0.f || v < s_split) ? v : s_split; }
+            }
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const float* ap = P.amax_in[i];
@@ -157,7 +166,8 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
                 const float a = (i < n_in && ap) ? *ap : 0.f;
                 sum_amax += a;
                 float inv_i;
-                const float s_i = sp ? *sp : scale_for_amax_q(a, inv_i);
+                float s_i = sp ? *sp : scale_for_amax_q(a, inv_i);
+                if (!sp && s_split != 0.f && s_split <= s_i && s_split * 256.f >= s_i) s_i = s_split;
                 if (tid == 0 && i < n_in) { sct[i] = s_i; sct[5 + i] = 1.f / s_i; sct[10 + i] = sp ? 1.f : 0.f; }
             }
             // scale of the planes this launch WRITES in split form: from a bound of the result, |y| <= max |bias| + 288 max |w| sum_i max |x_i|
