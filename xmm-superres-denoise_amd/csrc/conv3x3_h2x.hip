@@ -47,8 +47,7 @@ struct X3L {
     static constexpr int WOFF = NXB * X3_XB;            // 81,920
     static constexpr int BIAS = WOFF + 2 * WB;          // 122,880
     static constexpr int DESC = BIAS + 5 * 32 * 4;
-    static constexpr int SCALE = DESC + 16 * 8;         // per input plane: operand scale, its reciprocal, split-format flag (3 x 5 words)
-    static constexpr int BYTES = SCALE + 16 * 4;        // 123,712
+    static constexpr int BYTES = DESC + 16 * 8;         // 123,648
 };
 static_assert(X3L::BYTES <= 160 * 1024, "LDS");
 constexpr int X3_ROWB = HALO_W * 32;                // 1088
@@ -64,9 +63,7 @@ __device__ __forceinline__ void x3_split4(const f32x4& a, float s, u32x2& hi, u3
 // (conv3x3_h2x_kernel); KIND >= 0: an instance that holds ONE epilogue variant and, for the kinds whose launches never have a
 // LeakyReLU of their own (operand and masked kinds: conv5, trunk, every input-gradient launch), no LeakyReLU instructions
 // either -- its own register allocation, chosen by the launcher when every output chunk of the launch is of that kind.
-constexpr bool x3_kind_has_lrelu(int kind) { return kind < 0 || (kind & 127) == 0 || (kind & 127) == 64; }
-// (X3_SPLIT experiment) bit 7 of an instance's KIND: it WRITES its planes in split form (OutDesc::scale_out); kinds 64 and 48 only
-constexpr int X3_OUTSPLIT = 128;
+constexpr bool x3_kind_has_lrelu(int kind) { return kind < 0 || kind == 0 || kind == 64; }
 
 template <int KIND>
 __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
@@ -128,11 +125,8 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
     };
     const int rs0 = P.in[0].rs, ps0 = P.in[0].ps;
 
-    // operand scales (powers of two): ONE common scale for the input planes from the largest of their max |x| slots, the weight
-    // panels' from theirs; every wave computes the same values from the same slots (scalar loads).
-    // X3_SPLIT (experiment, instances only): an input plane may be stored in split form (PlaneIn::scale: its own power-of-two
-    // scale, chosen by its producer), so every plane has ITS scale -- table in LDS --, the accumulators are rescaled (exactly)
-    // when the K-loop moves to a plane with a different one, and the epilogue undoes the last plane's.
+    // operand scales (powers of two) from the max |x| of the input planes and of the weight panels; every wave computes the
+    // same values from the same slots (scalar loads)
     float sx, sw, inv_sx, inv_sw;
     {
         float ax = 0.f;
@@ -146,50 +140,8 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
         ax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ax)));
         sx = scale_for_amax(ax, inv_sx);
         sw = scale_for_amax(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, aw))), inv_sw);
-#ifdef X3_SPLIT
-        if constexpr (KIND >= 0) {
-            float* sct = reinterpret_cast<float*>(smem + L::SCALE);
-            float sum_amax = 0.f;
-            // the smallest scale among the launch's split planes: the fp32 planes (converted on the fly, any scale that cannot
-            // overflow will do) adopt it when it is within 2^8 of their own, so that most K-loops run on ONE scale and the
-            // accumulators are never rescaled
-            float s_split = 0.f;
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const float* sp = P.in[i].scale;
-                if (i < n_in && sp) { const float v = *sp; s_split = (s_split == 0.f || v < s_split) ? v : s_split; }
-            }
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const float* ap = P.amax_in[i];
-                const float* sp = P.in[i].scale;
-                const float a = (i < n_in && ap) ? *ap : 0.f;
-                sum_amax += a;
-                float inv_i;
-                float s_i = sp ? *sp : scale_for_amax_q(a, inv_i);
-                if (!sp && s_split != 0.f && s_split <= s_i && s_split * 256.f >= s_i) s_i = s_split;
-                if (tid == 0 && i < n_in) { sct[i] = s_i; sct[5 + i] = 1.f / s_i; sct[10 + i] = sp ? 1.f : 0.f; }
-            }
-            // scale of the planes this launch WRITES in split form: from a bound of the result, |y| <= max |bias| + 288 max |w| sum_i max |x_i|
-            // (no operand planes on these launches; LeakyReLU / the mask only shrink), quantised to steps of four binades so that the
-            // planes a later K-loop reads together mostly share it
-            if (P.out[0].scale_out) {
-                float bmax = 0.f;
-                if (P.bias) {
-                    for (int c = 0; c < 32 * n_out; ++c) bmax = __builtin_fmaxf(bmax, __builtin_fabsf(P.bias[c]));
-                }
-                float inv_o;
-                const float so = scale_for_amax_q(bmax + 288.f * aw * sum_amax * P.out[0].a1, inv_o);
-                if (tid == 0) { sct[15] = so; if (blockIdx.x == 0) { for (int j = 0; j < n_out; ++j) if (P.out[j].scale_out) *P.out[j].scale_out = so; } }
-            }
-            __syncthreads();
-            sx = sct[0]; inv_sx = sct[5];      // the first plane's: bias initialisation
-            sx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sx)));
-            inv_sx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, inv_sx)));
-        }
-#endif
     }
-    const float inv_s = inv_sx * inv_sw;      // undoes both scales in the epilogue (exact); X3_SPLIT: the LAST plane's, see epilogue
+    const float inv_s = inv_sx * inv_sw;      // undoes both scales in the epilogue (exact)
 
     if (loader) {
         // ============================ staging waves ============================
@@ -282,12 +234,10 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
         };
         auto asm_wait13 = [&](f32x4& u, f32x4& v) { asm volatile("s_waitcnt vmcnt(13)" : "+v"(u), "+v"(v) :: "memory"); };
         auto load_x_round = [&](int r, const i32x4& rs) { asm_load4(pin[r], xoff[r], rs); };
-        float sxi = sx;        // scale of the plane being staged (X3_SPLIT: per plane; else the common one)
-        bool rawi = false;     // that plane is stored in split form: its slots go to LDS as they are
         auto store_x_round = [&](int r, int xb) {   // xb: byte offset of the input buffer in LDS
             u32x2 hi, lo;
-            if ((abl & 1) || rawi) { hi[0] = __float_as_uint(pin[r][0]); hi[1] = __float_as_uint(pin[r][1]); lo[0] = __float_as_uint(pin[r][2]); lo[1] = __float_as_uint(pin[r][3]); }
-            else x3_split4(pin[r], sxi, hi, lo);
+            if (abl & 1) { hi[0] = __float_as_uint(pin[r][0]); hi[1] = __float_as_uint(pin[r][1]); lo[0] = __float_as_uint(pin[r][2]); lo[1] = __float_as_uint(pin[r][3]); }
+            else x3_split4(pin[r], sx, hi, lo);
             char* d = smem + xb + xlds[r];
             if (abl & 2) { asm volatile("" :: "v"(hi), "v"(lo), "v"(d)); return; }
             *reinterpret_cast<u32x2*>(d) = hi;
@@ -304,13 +254,6 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
 #pragma unroll
             for (int r = 0; r < X3_WR; ++r) dma_w_round(r, w0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef X3_SPLIT
-            if constexpr (KIND >= 0) {
-                const float* sct = reinterpret_cast<const float*>(smem + L::SCALE);
-                sxi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sct[0])));
-                rawi = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sct[10])) != 0;
-            }
-#endif
 #pragma unroll
             for (int r = 0; r < X3_XR; ++r) { asm volatile("" : "+v"(pin[r])); store_x_round(r, 0); }
         }
@@ -362,13 +305,6 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
                 }
             }
             const i32x4 xrs = x_rsrc(n2, t2, more2);
-#ifdef X3_SPLIT
-            if constexpr (KIND >= 0) {       // the plane of half-step it+1: its scale and whether its slots are already split
-                const float* sct = reinterpret_cast<const float*>(smem + L::SCALE);
-                sxi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sct[n1.i])));
-                rawi = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sct[10 + n1.i])) != 0;
-            }
-#endif
             // input of half-step it+1: registers -> the other buffer; then refill each register with half-step it+2
 #pragma unroll
             for (int r = 0; r < X3_XR; r += 2) {     // two rounds at a time: four independent split chains in flight
@@ -546,16 +482,7 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
         // a1e undoes the operand scales (a power of two: exact).  Without an accumulate / e1 operand between the two factors
         // a2 multiplies the same value and is folded in (every such launch of the engine has a2 = 1: exact there)
         constexpr bool fold_a2 = !decltype(has_acc)::value && !decltype(has_e1)::value;
-        float inv_se = inv_s;
-        float s_out = 0.f;       // X3_SPLIT: this plane is written in split form with this scale (0: fp32)
-#ifdef X3_SPLIT
-        if constexpr (KIND >= 0) {
-            const float* sct = reinterpret_cast<const float*>(smem + L::SCALE);
-            inv_se = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sct[5 + n_in - 1]))) * inv_sw;
-            if constexpr ((KIND & X3_OUTSPLIT) != 0) s_out = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sct[15])));
-        }
-#endif
-        const float a1e = fold_a2 ? o.a1 * inv_se * o.a2 : o.a1 * inv_se;
+        const float a1e = fold_a2 ? o.a1 * inv_s * o.a2 : o.a1 * inv_s;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int y = T.y0 + wv * 2 + r;
@@ -604,16 +531,6 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) obits |= (v[t] > 0.f ? 1u : 0u) << (4 * q + t);
                 }
-#ifdef X3_SPLIT
-                if constexpr (KIND >= 0 && (KIND & X3_OUTSPLIT) != 0) {     // the slot as [4 x h | 4 x l]
-                    unsigned int h0, l0, h1, l1;      // (pair by pair: the four-value form needs eight temporaries at once and spills here)
-                    split2_f16_pair(v[0], v[1], s_out, h0, l0);
-                    split2_f16_pair(v[2], v[3], s_out, h1, l1);
-                    f32x4 w;
-                    w[0] = __uint_as_float(h0); w[1] = __uint_as_float(h1); w[2] = __uint_as_float(l0); w[3] = __uint_as_float(l1);
-                    pend[4 * r + q] = w;
-                } else
-#endif
                 pend[4 * r + q] = v;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) run_max = __builtin_fmaxf(run_max, valid ? __builtin_fabsf(v[t]) : 0.f);   // select, no branch
@@ -637,12 +554,12 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
         const int kind = (o.accumulate ? 1 : 0) | (o.e1 ? 2 : 0) | (o.e2 ? 4 : 0) | (o.e3 ? 8 : 0) | (o.mask ? 16 : 0);
         // (bits_out with operands other than none, bits_in without mask: not in the engine's plans -> rejected by the launcher)
         if constexpr (KIND == 0) epilogue_v(o, T, N{}, N{}, N{}, N{}, N{}, N{}, N{}, N{});
-        else if constexpr ((KIND & 127) == 64) epilogue_v(o, T, N{}, N{}, N{}, N{}, N{}, N{}, N{}, Y{});
+        else if constexpr (KIND == 64) epilogue_v(o, T, N{}, N{}, N{}, N{}, N{}, N{}, N{}, Y{});
         else if constexpr (KIND == 2) epilogue_v(o, T, N{}, Y{}, N{}, N{}, N{}, N{}, N{}, N{});
         else if constexpr (KIND == 6) epilogue_v(o, T, N{}, Y{}, Y{}, N{}, N{}, N{}, N{}, N{});
         else if constexpr (KIND == 14) epilogue_v(o, T, N{}, Y{}, Y{}, Y{}, N{}, N{}, N{}, N{});
         else if constexpr (KIND == 16) epilogue_v(o, T, N{}, N{}, N{}, N{}, Y{}, N{}, N{}, N{});
-        else if constexpr ((KIND & 127) == 48) epilogue_v(o, T, N{}, N{}, N{}, N{}, Y{}, N{}, Y{}, N{});
+        else if constexpr (KIND == 48) epilogue_v(o, T, N{}, N{}, N{}, N{}, Y{}, N{}, Y{}, N{});
         else {
             static_assert(KIND < 0, "no epilogue variant for this kind");
             switch (kind | ((o.mask && o.bits_in) ? 32 : 0) | (o.bits_out ? 64 : 0)) {
@@ -684,20 +601,6 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
         const bool more1 = (it + 1 < items);
         X3_TICK(1);
         if (cur.i == 0 && cur.s2 == 0) init_acc(cur.j);
-#ifdef X3_SPLIT
-        if constexpr (KIND >= 0) {
-            if (cur.i > 0 && cur.s2 == 0) {      // the K-loop moves to another plane: accumulators into ITS scale's units (a power of two: exact)
-                const float* sct = reinterpret_cast<const float*>(smem + L::SCALE);
-                const float ratio = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sct[cur.i] * sct[5 + cur.i - 1])));
-                if (ratio != 1.f) {
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) { acc[r][q] *= ratio; accx[r][q] *= ratio; }
-                }
-            }
-        }
-#endif
         compute(smem + xpar * X3_XB, it & 1, pending);
         xpar = (xpar + 1 == L::NXB) ? 0 : xpar + 1;
         pending = false;
@@ -764,7 +667,7 @@ template <int KIND> __global__ __launch_bounds__(X3_THREADS) void conv3x3_h2x_ki
 #ifndef X3_KINDS
 #define X3_KINDS 68      // kinds 2 (one operand plane) and 48 (compact-mask read)
 #endif
-constexpr int X3_KIND_LIST[7] = {0, 64, 2, 6, 14, 16, 48};     // (+ X3_OUTSPLIT for kinds 64 and 48 when the launch writes split planes)
+constexpr int X3_KIND_LIST[7] = {0, 64, 2, 6, 14, 16, 48};
 
 static PerDevice g_once;
 
@@ -780,9 +683,6 @@ hipError_t launch_conv3x3_h2x(const ConvParams& p, hipStream_t stream)
         hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X3L::BYTES);
 #define X3_ATTR(K) if (r == hipSuccess) r = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2x_kind_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, X3L::BYTES)
         X3_ATTR(0); X3_ATTR(64); X3_ATTR(2); X3_ATTR(6); X3_ATTR(14); X3_ATTR(16); X3_ATTR(48);
-#ifdef X3_SPLIT
-        X3_ATTR(64 + X3_OUTSPLIT); X3_ATTR(48 + X3_OUTSPLIT);
-#endif
 #undef X3_ATTR
         return r;
     }, &ncu);
@@ -813,20 +713,6 @@ hipError_t launch_conv3x3_h2x(const ConvParams& p, hipStream_t stream)
         for (int j = 0; j < p.n_out; ++j) if (p.out[j].slope != 1.f) kind = -1;
     int idx = -1;
     for (int i = 0; i < 7; ++i) if (X3_KIND_LIST[i] == kind && ((X3_KINDS >> i) & 1)) idx = i;
-#ifdef X3_SPLIT
-    {   // split-plane storage: inputs in split form need an instance (the catch-all kernel has no such path); outputs in split
-        // form exist for kinds 64 and 48 only, for every output chunk or none
-        bool in_split = false, out_split = p.out[0].scale_out != nullptr;
-        for (int i = 0; i < p.n_in; ++i) in_split |= p.in[i].scale != nullptr;
-        for (int j = 0; j < p.n_out; ++j) if ((p.out[j].scale_out != nullptr) != out_split) return hipErrorInvalidValue;
-        if ((in_split || out_split) && idx < 0) return hipErrorInvalidValue;
-        if (out_split) {
-            if (kind == 64) { hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<64 + X3_OUTSPLIT>, g, b, X3L::BYTES, stream, p); return hipGetLastError(); }
-            if (kind == 48) { hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<48 + X3_OUTSPLIT>, g, b, X3L::BYTES, stream, p); return hipGetLastError(); }
-            return hipErrorInvalidValue;
-        }
-    }
-#endif
     switch (idx) {
     case 0: hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<0>, g, b, X3L::BYTES, stream, p); break;
     case 1: hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<64>, g, b, X3L::BYTES, stream, p); break;

@@ -99,12 +99,7 @@ constexpr bool v3_deal_is_a_partition()
 }
 static_assert(v3_deal_is_a_partition(), "every (product, tap) accumulator is held by exactly one wave");
 
-// XRAW / GRAW (experiment -DX3_SPLIT, split-plane storage): the X planes / the G planes of the launch are stored in split form -- every
-// 16-byte slot already holds [4 x h | 4 x l] and goes to LDS as it is, the scale is the one the plane's producer published
-// (PlaneIn::scale).  Compile-time, one kernel instance each: a run-time choice inside the staging loop makes hipcc copy load
-// destinations that are still in flight (the ISA check catches it); the launcher requires one format per launch and operand.
-template <bool XRAW, bool GRAW>
-__device__ __forceinline__ void wgrad_h2x_body(const WgradParams& P)
+__global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -162,17 +157,6 @@ __device__ __forceinline__ void wgrad_h2x_body(const WgradParams& P)
         for (int i = 0; i < 4; ++i) if (i == n && P.amax_g[i]) ag = *P.amax_g[i];
         sx = scale_for_amax(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ax))), inv_sx);
         sg = scale_for_amax(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ag))), inv_sg);
-    }
-    constexpr bool xraw = XRAW, graw = GRAW;
-    if constexpr (XRAW || GRAW) {
-        const float* xsp = nullptr;
-        const float* gsp = nullptr;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) if (i == j) xsp = P.x[i].scale;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) if (i == n) gsp = P.g[i].scale;
-        if (XRAW && xsp) { sx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *xsp))); inv_sx = 1.f / sx; }
-        if (GRAW && gsp) { sg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *gsp))); inv_sg = 1.f / sg; }
     }
     const float inv_s = inv_sx * inv_sg;
 
@@ -264,7 +248,7 @@ __device__ __forceinline__ void wgrad_h2x_body(const WgradParams& P)
 #endif
         auto store_x = [&](int r, int buf) {
             u32x2 hi, lo;
-            if ((abl & 1) || xraw) { hi[0] = __float_as_uint(px[r][0]); hi[1] = __float_as_uint(px[r][1]); lo[0] = __float_as_uint(px[r][2]); lo[1] = __float_as_uint(px[r][3]); }
+            if (abl & 1) { hi[0] = __float_as_uint(px[r][0]); hi[1] = __float_as_uint(px[r][1]); lo[0] = __float_as_uint(px[r][2]); lo[1] = __float_as_uint(px[r][3]); }
             else split2_f16x4(px[r], sx, hi, lo);
             const bool sink = (r == RL && !live6);
 #ifdef V3_SHAPE16
@@ -278,7 +262,7 @@ __device__ __forceinline__ void wgrad_h2x_body(const WgradParams& P)
         };
         auto store_g = [&](int r, int buf) {
             u32x2 hi, lo;
-            if ((abl & 1) || graw) { hi[0] = __float_as_uint(pg[r][0]); hi[1] = __float_as_uint(pg[r][1]); lo[0] = __float_as_uint(pg[r][2]); lo[1] = __float_as_uint(pg[r][3]); }
+            if (abl & 1) { hi[0] = __float_as_uint(pg[r][0]); hi[1] = __float_as_uint(pg[r][1]); lo[0] = __float_as_uint(pg[r][2]); lo[1] = __float_as_uint(pg[r][3]); }
             else split2_f16x4(pg[r], sg, hi, lo);
 #ifdef V3_SHAPE16
             char* d = smem + buf + V3_G_OFF + gh0 + r * (V3_LT * 4);
@@ -288,17 +272,6 @@ __device__ __forceinline__ void wgrad_h2x_body(const WgradParams& P)
             if (abl & 2) { asm volatile("" :: "v"(hi), "v"(lo), "v"(d)); bsum += pg[r]; return; }
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + V3_GT) = lo;
-            if (graw) {      // the slot holds [4 x h | 4 x l]: the bias gradient's terms are h + l * 2^-11 (in units of the plane's scale; undone below)
-                float g0, g1, g2, g3;
-                const float k = 0x1p-11f;
-                asm("v_fma_mix_f32 %0, %4, %6, %5 op_sel_hi:[1,0,1]\n\t"
-                    "v_fma_mix_f32 %1, %4, %6, %5 op_sel:[1,0,1] op_sel_hi:[1,0,1]\n\t"
-                    "v_fma_mix_f32 %2, %7, %6, %8 op_sel_hi:[1,0,1]\n\t"
-                    "v_fma_mix_f32 %3, %7, %6, %8 op_sel:[1,0,1] op_sel_hi:[1,0,1]"
-                    : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3)
-                    : "v"(lo[0]), "v"(hi[0]), "s"(k), "v"(lo[1]), "v"(hi[1]));
-                bsum[0] += g0; bsum[1] += g1; bsum[2] += g2; bsum[3] += g3;
-            } else
             bsum += pg[r];
         };
 
@@ -540,7 +513,7 @@ __device__ __forceinline__ void wgrad_h2x_body(const WgradParams& P)
     if (j == 0) { // bias gradient: staging thread lt staged channels 4*(lt&7)..+3 of the G tiles
         if (loader) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) red[tid * 4 + i] = graw ? bsum[i] * inv_sg : bsum[i];
+            for (int i = 0; i < 4; ++i) red[tid * 4 + i] = bsum[i];
         }
         __syncthreads();
         if (tid < 32) {
@@ -552,22 +525,12 @@ __device__ __forceinline__ void wgrad_h2x_body(const WgradParams& P)
     }
 }
 
-__global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams P) { wgrad_h2x_body<false, false>(P); }
-#ifdef X3_SPLIT
-template <bool XRAW, bool GRAW> __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_split_kernel(const WgradParams P) { wgrad_h2x_body<XRAW, GRAW>(P); }
-#endif
-
 hipError_t launch_wgrad_h2x(const WgradParams& p, hipStream_t stream)
 {
     static PerDevice once_;
     hipError_t e = once_.once([]() {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h2x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS_BYTES);
-#ifdef X3_SPLIT
-        if (r == hipSuccess) r = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h2x_split_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS_BYTES);
-        if (r == hipSuccess) r = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h2x_split_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS_BYTES);
-        if (r == hipSuccess) r = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h2x_split_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS_BYTES);
-#endif
-        return r;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h2x_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS_BYTES);
     }, nullptr);
     if (e != hipSuccess) return e;
     if (p.nparts & 7) return hipErrorInvalidValue;
@@ -577,18 +540,6 @@ hipError_t launch_wgrad_h2x(const WgradParams& p, hipStream_t stream)
     for (int i = 0; i < p.n_in; ++i) if ((long long)p.H * p.x[i].rs * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     for (int i = 0; i < p.n_g; ++i) if ((long long)p.H * p.g[i].rs * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     const dim3 g(p.nparts * p.n_in * p.n_g), b(V3_THREADS);
-    // storage format: one per launch and operand (the engine cuts a conv's weight-gradient into launches by format)
-    const bool xraw = p.x[0].scale != nullptr, graw = p.g[0].scale != nullptr;
-    for (int i = 0; i < p.n_in; ++i) if ((p.x[i].scale != nullptr) != xraw) return hipErrorInvalidValue;
-    for (int i = 0; i < p.n_g; ++i) if ((p.g[i].scale != nullptr) != graw) return hipErrorInvalidValue;
-#ifdef X3_SPLIT
-    if (xraw && graw) hipLaunchKernelGGL((wgrad_h2x_split_kernel<true, true>), g, b, V3_LDS_BYTES, stream, p);
-    else if (xraw) hipLaunchKernelGGL((wgrad_h2x_split_kernel<true, false>), g, b, V3_LDS_BYTES, stream, p);
-    else if (graw) hipLaunchKernelGGL((wgrad_h2x_split_kernel<false, true>), g, b, V3_LDS_BYTES, stream, p);
-    else
-#else
-    if (xraw || graw) return hipErrorInvalidValue;
-#endif
     hipLaunchKernelGGL(wgrad_h2x_kernel, g, b, V3_LDS_BYTES, stream, p);
     return hipGetLastError();
 }

@@ -198,9 +198,6 @@ struct Builder {
     // a plane_amax launch in front of the first consumer); a view dies when its buffer is handed out again
     typedef std::tuple<uintptr_t, int, int> ViewKey;
     std::map<ViewKey, float*> amax_valid;
-    // -DX3_SPLIT (experiment: split-plane storage): plane views that are STORED in split form, with the slot their
-    // producer publishes the scale to; dropped like the max-|x| slots when the buffer is written again
-    std::map<ViewKey, float*> split_valid;
     Builder(xsd_engine* e_, int B_, int H_, int W_, bool train_, uintptr_t base_)
         : e(e_), B(B_), H(H_), W(W_), train(train_), base(base_), freelist(8) {}
 
@@ -218,15 +215,6 @@ struct Builder {
             const uintptr_t k = std::get<0>(it->first);
             if (k >= lo && k < lo + bytes) it = amax_valid.erase(it); else ++it;
         }
-        for (auto it = split_valid.begin(); it != split_valid.end();) {
-            const uintptr_t k = std::get<0>(it->first);
-            if (k >= lo && k < lo + bytes) it = split_valid.erase(it); else ++it;
-        }
-    }
-    const float* split_scale_of(const PlaneIn& v) const
-    {
-        auto it = split_valid.find(ViewKey(reinterpret_cast<uintptr_t>(v.p), v.rs, v.ps));
-        return it == split_valid.end() ? nullptr : it->second;
     }
     // slot of an input view; if nobody has reported it yet, `pre` gets the reduction launch
     float* slot_of(const PlaneIn& v, int Hv, int Wv, std::vector<Launch>& pre)
@@ -292,13 +280,13 @@ struct Builder {
     }
     PlaneIn std_in(const float* p, int level) const
     {
-        PlaneIn r; r.p = p; r.ps = 32; r.rs = (W << level) * 32; r.bs = (long long)(H << level) * (W << level) * 32; r.scale = nullptr; return r;
+        PlaneIn r; r.p = p; r.ps = 32; r.rs = (W << level) * 32; r.bs = (long long)(H << level) * (W << level) * 32; return r;
     }
     // sub-pixel (i,j) view at `level` of a plane stored at level+1 (PixelShuffle(2), generator_rrdb.py:97)
     PlaneIn shuf_in(const float* hr, int level, int n) const
     {
         const int Wl = W << level, Hl = H << level;
-        PlaneIn r; r.scale = nullptr; r.p = hr + ((long long)(n >> 1) * 2 * Wl + (n & 1)) * 32; r.ps = 64; r.rs = 4 * Wl * 32;
+        PlaneIn r; r.p = hr + ((long long)(n >> 1) * 2 * Wl + (n & 1)) * 32; r.ps = 64; r.rs = 4 * Wl * 32;
         r.bs = (long long)4 * Hl * Wl * 32; return r;
     }
     void std_out(OutDesc& o, float* p, int level) const
@@ -343,7 +331,6 @@ struct Builder {
         std::vector<Launch> pre;     // math mode 4: reductions for input planes nobody has reported yet
         if (e->math == 4) {
             for (int i = 0; i < p.n_in; ++i) p.amax_in[i] = slot_of(p.in[i], p.H, p.W, pre);
-            for (int i = 0; i < p.n_in; ++i) p.in[i].scale = split_scale_of(p.in[i]);
             for (int j = 0; j < p.n_out; ++j) {   // this launch reports its own outputs
                 OutDesc& o = p.out[j];
                 // every view of the plane this launch writes loses its slot: a shuffled view (shuf_out) is one of four that
@@ -351,15 +338,6 @@ struct Builder {
                 invalidate_range(reinterpret_cast<uintptr_t>(o.p), (size_t)p.B * (size_t)o.bs * sizeof(float));
                 o.amax = new_slot();
                 amax_valid[ViewKey(reinterpret_cast<uintptr_t>(o.p), o.rs, o.ps)] = o.amax;
-#ifdef X3_SPLIT
-                // the planes only MFMA kernels read -- the dense blocks' activations x1..x4 (compact-mask output) and the gradient planes
-                // masked by them (compact-mask input) -- are stored in split form; the skip-path planes stay fp32
-                if (e->planes == 1 && e->cfg.in_channels == 1 && e->cfg.out_channels == 1 && o.ps == 32 && o.rs == p.std_rs &&
-                    !o.accumulate && !o.e1 && !o.e2 && !o.e3 && (o.bits_out || (o.mask && o.bits_in))) {
-                    o.scale_out = new_slot();
-                    split_valid[ViewKey(reinterpret_cast<uintptr_t>(o.p), o.rs, o.ps)] = o.scale_out;
-                }
-#endif
             }
         }
         return [eng, p, pre, bias_from_params, bias_off, flop, bytes](hipStream_t s) mutable {
@@ -375,19 +353,6 @@ struct Builder {
     void wgrad_launch(std::vector<Launch>& ops, int level, const std::vector<PlaneIn>& xs, const std::vector<PlaneIn>& gs,
                       const ConvW& cw, float scale, int j0 = 0, int n0 = 0, int plane = 0)
     {
-#ifdef X3_SPLIT
-        // split-plane storage: the kernel takes one storage format per launch and operand -- a conv whose input planes differ in
-        // format (x0 is fp32, x1.. are split) gets one launch per run of equal format (WgradReduceParams::j0 places the blocks)
-        if (e->math == 4 && xs.size() > 1) {
-            size_t cut = 1;
-            while (cut < xs.size() && (split_scale_of(xs[cut]) != nullptr) == (split_scale_of(xs[0]) != nullptr)) ++cut;
-            if (cut < xs.size()) {
-                wgrad_launch(ops, level, std::vector<PlaneIn>(xs.begin(), xs.begin() + cut), gs, cw, scale, j0, n0, plane);
-                wgrad_launch(ops, level, std::vector<PlaneIn>(xs.begin() + cut, xs.end()), gs, cw, scale, j0 + (int)cut, n0, plane);
-                return;
-            }
-        }
-#endif
         xsd_engine* eng = e;
         WgradParams wp;
         memset(&wp, 0, sizeof(wp));
@@ -412,8 +377,6 @@ struct Builder {
         if (e->math == 4) {
             for (size_t i = 0; i < xs.size(); ++i) wp.amax_x[i] = slot_of(xs[i], wp.H, wp.W, pre);
             for (size_t i = 0; i < gs.size(); ++i) wp.amax_g[i] = slot_of(gs[i], wp.H, wp.W, pre);
-            for (size_t i = 0; i < xs.size(); ++i) wp.x[i].scale = split_scale_of(xs[i]);
-            for (size_t i = 0; i < gs.size(); ++i) wp.g[i].scale = split_scale_of(gs[i]);
         }
         WgradReduceParams rp;
         memset(&rp, 0, sizeof(rp));

@@ -58,10 +58,6 @@ struct PlaneIn {
     long long bs; // batch stride (floats)
     int rs;       // row stride (floats)
     int ps;       // pixel stride (floats)
-    // Split-plane storage (math mode 4, experiment XSD_SPLIT_PLANES): non-null = every 16-byte slot of this plane (four
-    // channels of one pixel) holds [4 x h | 4 x l] -- the two fp16 terms of x * S, l scaled 2^11 -- instead of four fp32 values,
-    // and *scale is S (a power of two published by the producing launch).  Same addresses as an fp32 plane.
-    const float* scale;
 };
 
 // One 32-channel output chunk and its fused epilogue:
@@ -85,8 +81,6 @@ struct OutDesc {
     const unsigned short* bits_in;
     // math mode 4 (f16x3): slot that receives max |stored value| of this plane (atomic max of the float bits), or null
     float* amax;
-    // non-null: store this plane in split form (PlaneIn::scale) and publish its scale here (launches without operand planes only)
-    float* scale_out;
 };
 
 struct ConvParams {

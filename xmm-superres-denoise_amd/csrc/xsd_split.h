@@ -118,19 +118,4 @@ __device__ __forceinline__ float scale_for_amax(float amax, float& inv)
     return __builtin_bit_cast(float, (unsigned int)(127 + k) << 23);
 }
 
-// the same with the exponent rounded DOWN to a multiple of four binades (amax * s in [2^10, 2^14)): planes whose maxima lie within
-// a factor of 16 of each other mostly get the same scale (split-plane storage: a K-loop over planes with equal scales needs no
-// accumulator rescale); the two-term split keeps 22-23 bits for every element above 2^-24 of the plane's maximum
-__device__ __forceinline__ float scale_for_amax_q(float amax, float& inv)
-{
-    const unsigned int u = __builtin_bit_cast(unsigned int, amax);
-    const int ex = (int)((u >> 23) & 0xff);
-    int k = 140 - ex;
-    if (ex == 0 || ex == 255) k = 0;
-    k = (k >= 0 ? k : k - 3) / 4 * 4;       // floor to a multiple of 4
-    k = k > 60 ? 60 : (k < -60 ? -60 : k);
-    inv = __builtin_bit_cast(float, (unsigned int)(127 - k) << 23);
-    return __builtin_bit_cast(float, (unsigned int)(127 + k) << 23);
-}
-
 } // namespace xsd
