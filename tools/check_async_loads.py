@@ -4,7 +4,7 @@ csrc/conv3x3_h2x.hip, csrc/wgrad_s3x.hip, csrc/wgrad_h2x.hip).
 The staging loop issues its global loads and their `s_waitcnt vmcnt(14)` from inline asm, so hipcc does not know that a
 load's destination registers are written asynchronously.  That is only correct if, in the generated code,
   * the loop holds exactly N asm vector-memory operations (15 for the conv -- register loads and, with the weights by
-    LDS-DMA, `... lds` pieces --, 11 / 19 for the weight gradients) and no other vector-memory instruction or wait
+    LDS-DMA, `... lds` pieces --, 11 / 17 for the weight gradients) and no other vector-memory instruction or wait
     (anything else would shift the hand-made count),
   * with the operations retiring in issue order and `vmcnt(n)` returning when all but the youngest n have (the loop is
     simulated from the state the prologue leaves), no instruction touches a load's destination registers while that
@@ -22,7 +22,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "xmm-superres-denoise_amd", "csrc")
-KERNELS = (("conv3x3_s3x.hip", 15), ("conv3x3_h2x.hip", 15), ("wgrad_s3x.hip", 11), ("wgrad_h2x.hip", 19))     # source, counted loads per pass of the staging loop
+KERNELS = (("conv3x3_s3x.hip", 15), ("conv3x3_h2x.hip", 15), ("wgrad_s3x.hip", 11), ("wgrad_h2x.hip", 17))     # source, counted loads per pass of the staging loop
 
 
 def regs_of(tok):

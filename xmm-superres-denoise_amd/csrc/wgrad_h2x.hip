@@ -46,34 +46,40 @@ constexpr int V3_MW = 8;                                              // MFMA wa
 constexpr int V3_LT = 64 * V3_LWAVES;                                 // staging threads (waves 0 .. V3_LWAVES-1)
 constexpr int V3_THREADS = V3_LT + 64 * V3_MW;                        // 768
 constexpr int V3_HPX = (V3_TH + 2) * HALO_W;                          // 340 halo pixels
-constexpr int V3_X_SLOTS = V3_HPX * 8;                                // 2720 (pixel, channel quad) slots
-constexpr int V3_X_ROUNDS = (V3_X_SLOTS + V3_LT - 1) / V3_LT;         // 11
+// Round 4, second half: a workgroup walks its tiles DOWN a 32-pixel column strip, so the two top halo rows of a tile are the two
+// bottom halo rows of the tile before it -- already split, already in the other LDS buffer.  The staging waves fetch and split
+// only the V3_TH rows below them (LDS rows 2 .. V3_TH+1) and copy the two top rows LDS -> LDS (8.7 KB per tile): 9 X rounds
+// instead of 11, 17 loads per tile and staging thread instead of 19.  The first tile of a workgroup's chunk is staged whole by
+// the prologue; a strip start inside the chunk is preceded by a WARM-UP item, the virtual tile ty = -1 of that strip (rows
+// -7 .. 0: everything above the image fails the buffer range check and reads as zeros, row 0 is real) with an empty G
+// descriptor (its products are zeros) -- one item in tilesY + 1, branch-free in the counted-load loop.
+constexpr int V3_X_SLOTS = V3_TH * HALO_W * 8;                        // 2176 (pixel, channel quad) slots of the fetched rows
+constexpr int V3_X_ROUNDS = (V3_X_SLOTS + V3_LT - 1) / V3_LT;         // 9
+constexpr int V3_TOP_SLOTS = 2 * HALO_W * 8;                          // 544: the two top rows (prologue only)
+constexpr int V3_TOP_ROUNDS = (V3_TOP_SLOTS + V3_LT - 1) / V3_LT;     // 3
 constexpr int V3_G_SLOTS = V3_TH * TILE_W * 8;                        // 2048
 constexpr int V3_G_ROUNDS = V3_G_SLOTS / V3_LT;                       // 8
-constexpr int V3_NL = V3_X_ROUNDS + V3_G_ROUNDS;                      // 19 loads per tile and staging thread
-constexpr int V3_XT = V3_HPX * 64;                                    // 21,760 B per X term image
-#ifndef V3_SHAPE32
-#define V3_SHAPE16 1
-#endif
-#ifdef V3_SHAPE16
-// A term image is [channel half][pixel][16 x f16] (32-B records); the 32 lanes of a
-// transposing read then take 256 contiguous bytes (8 pixels of one channel half): conflict-free at any pixel offset.  The
-// half-image strides are = 128 mod 256 so that a staging write (lanes 0-31: 4 pixels x both halves) is conflict-free too.
-constexpr int V3_XH = V3_HPX * 32;                                    // 10,880 B per X half image (= 128 mod 256)
-constexpr int V3_GH = V3_TH * TILE_W * 32 + 128;                      // 8,320 B per G half image
-constexpr int V3_GT = 2 * V3_GH;                                      // 16,640 B per G term image
-static_assert(V3_XH % 256 == 128 && V3_GH % 256 == 128 && 2 * V3_XH == V3_XT, "half-image strides");
-#else
-// -DV3_SHAPE32 (v_mfma_f32_32x32x16_f16: K = 16 pixels, one MFMA per unit and step): a term image is [pixel][32 x f16] (64-B records)
-constexpr int V3_GT = V3_TH * TILE_W * 64;                            // 16,384 B per G term image
-#endif
-constexpr int V3_G_OFF = 2 * V3_XT;                                   // 43,520
-constexpr int V3_BUF = V3_G_OFF + 2 * V3_GT;                          // 76,288 B per buffer
+constexpr int V3_NL = V3_X_ROUNDS + V3_G_ROUNDS;                      // 17 loads per tile and staging thread
+// A term image is [channel half][pixel][16 x f16] (32-B records); the 32 lanes of a transposing read then take 256 contiguous
+// bytes (8 pixels of one channel half): conflict-free at any pixel offset.  A staging write (`ds_write_b64`: 16-lane groups over
+// 32 four-byte banks, MI355X_MICROARCH.md LDS table) covers 2 pixels x both channel halves x 32 B per group: the half-image
+// strides are = 64 mod 128 so that the four 32-byte pieces of a group fall into four different bank octets.  (Until round 4
+// the strides were = 128 mod 256 -- right for 64 banks, 2-way conflicted on 32: SQ_LDS_BANK_CONFLICT 7.2e9 of 3.1e10 LDS cycles,
+// 570 cycles per tile = the 152 staging writes x 4 extra cycles; profiles/r04_pmc_sq_f16x3_dn_train_b32.txt.)
+constexpr int V3_XH = V3_HPX * 32 + 64;                               // 10,944 B per X half image
+constexpr int V3_XT = 2 * V3_XH;                                      // 21,888 B per X term image
+constexpr int V3_GH = V3_TH * TILE_W * 32 + 64;                       // 8,256 B per G half image
+constexpr int V3_GT = 2 * V3_GH;                                      // 16,512 B per G term image
+static_assert(V3_XH % 128 == 64 && V3_GH % 128 == 64 && V3_XH % 16 == 0, "half-image strides");
+constexpr int V3_G_OFF = 2 * V3_XT;                                   // 43,776
+constexpr int V3_BUF = V3_G_OFF + 2 * V3_GT;                          // 76,800 B per buffer
 constexpr int V3_SINK = 2 * V3_BUF;                                   // writes of exhausted slots land behind the buffers (hi at +0, lo at +512)
+constexpr int V3_ROW2 = 2 * HALO_W * 32;                              // 2,176 B: two halo rows of one half image
+constexpr int V3_CPY_UNITS = 4 * (V3_ROW2 / 16);                      // 544 16-byte units: {X_h, X_l} x {channel half} x two rows
+constexpr int V3_CPY_ROUNDS = (V3_CPY_UNITS + V3_LT - 1) / V3_LT;     // 3
 constexpr int V3_RED = 27 * 4096;                                     // final reduction: one 4 KiB slab per accumulator
-constexpr int V3_LDS_BYTES = (V3_SINK + 1024) > V3_RED ? (V3_SINK + 1024) : V3_RED;     // 153,600
+constexpr int V3_LDS_BYTES = (V3_SINK + 1024) > V3_RED ? (V3_SINK + 1024) : V3_RED;     // 154,624
 static_assert(V3_LDS_BYTES <= 160 * 1024, "LDS");
-
 
 // Which of the 27 accumulators ("units", u = 9 * product + tap; product 0 = Xh*Gh, 1 = Xh*Gl, 2 = Xl*Gh; tap = 3 dy + dx) MFMA wave w
 // holds in slot q: slots 0..2 = the column triple (product, dx) of the wave, taps dy = q; slot 3 (waves 0..2 only) = one tap of
@@ -107,10 +113,6 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wid < V3_LWAVES;   // wave-uniform role
-#ifndef V3_SHAPE16
-    const int h = lane >> 5;
-    const int l31 = lane & 31;
-#endif
 
     // 1-D grid decode (as in wgrad_s3x.hip): the n_in workgroups that read the SAME G tiles have linear ids 8 apart -> one XCD
     const int lin = blockIdx.x;
@@ -122,7 +124,19 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
     const int n = rest / parts8;                      // G chunk
     const int tilesY = (P.H + V3_TH - 1) / V3_TH;
     const int ntiles = P.B * tilesY * P.tilesX;
-    const int my_tiles = part < ntiles ? (ntiles - part + P.nparts - 1) / P.nparts : 0;
+    // This workgroup's chunk: the tiles [t_lo, t_hi) of the order (strip = b * tilesX + tx, ty) with ty fastest, i.e. down the
+    // column strips.  Its ITEMS are those tiles plus one warm-up item (ty = -1, no G) in front of every strip that starts
+    // inside the chunk: item k sits at position q0 + k of the strips laid end to end with tilesY + 1 positions each
+    // (position p of a strip <-> ty = p - 1).
+    const int t_lo = (int)((long long)part * ntiles / P.nparts), t_hi = (int)((long long)(part + 1) * ntiles / P.nparts);
+    const int SE = tilesY + 1;
+    const int strip0 = t_lo / tilesY;
+    const int q0 = t_lo - strip0 * tilesY + 1;
+    int my_tiles = 0;                                 // items, warm-ups included
+    if (t_hi > t_lo) {
+        const int se = (t_hi - 1) / tilesY;
+        my_tiles = (se - strip0) * SE + ((t_hi - 1) - se * tilesY + 1) - q0 + 1;
+    }
 
     auto lds_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -160,12 +174,16 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
     }
     const float inv_s = inv_sx * inv_sg;
 
-    constexpr int NU = 4;              // accumulators ("units") per MFMA wave: 27 = 4 + 4 + 4 + 3 + 3 + 3 + 3 + 3
-#ifdef V3_SHAPE16
-    f32x4 acc[NU][2][2];               // [unit][input-channel half][output-channel half]: four 16x16 tiles per unit
+#if defined(XSD_DIAG) && defined(XSD_ABL)   // timing experiments: a COMPILE-TIME constant (-DXSD_DIAG -DXSD_ABL=n builds; a run-time
+                                            // value puts the hand-counted loads and waits under branches hipcc cannot keep exact)
+    constexpr int abl = XSD_ABL;     // staging waves: 1 no split, 2 no LDS writes, 4 no loads and no counted waits, 128 nothing but the barrier;
+                                     // MFMA waves: 32 no MFMAs (fragment reads only), 256 no fragment reads (MFMAs only), 64 nothing but the barrier
+                                     // (results are garbage: read the stamps' CYCLES, not milliseconds -- degenerate operands raise the clock)
 #else
-    f32x16 acc[NU];
+    constexpr int abl = 0;
 #endif
+    constexpr int NU = 4;              // accumulators ("units") per MFMA wave: 27 = 4 + 4 + 4 + 3 + 3 + 3 + 3 + 3
+    f32x4 acc[NU][2][2];               // [unit][input-channel half][output-channel half]: four 16x16 tiles per unit
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f}; // staging thread: its 4 channels (lt & 7) of the G tiles it stages
 
     if (loader) {
@@ -177,7 +195,8 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
         const PlaneIn xp = P.x[j];
         const PlaneIn gp = P.g[n];
         constexpr int OOR = (int)0x80000000;          // lane offset that fails every range check -> the load returns 0
-        // per-slot constants: X round r -> halo pixel (hy, hx), channel quad c; byte offset relative to the tile origin
+        // per-slot constants: X round r -> pixel (hy, hx) of the FETCHED rows (LDS row hy + 2), channel quad c; byte offset
+        // relative to the tile origin (= the first fetched row, image row y0 + 1, column x0 - 1)
         int xrel[V3_X_ROUNDS], xhx[V3_X_ROUNDS], grel[V3_G_ROUNDS], ggx[V3_G_ROUNDS];
 #pragma unroll
         for (int r = 0; r < V3_X_ROUNDS; ++r) {
@@ -194,15 +213,20 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             grel[r] = ((p >> 5) * gp.rs + (p & 31) * gp.ps + c * 4) * 4;
             ggx[r] = p & 31;
         }
-#ifdef V3_SHAPE16
         const int lds0 = (lt >> 3) * 32 + (lt & 3) * 8;        // + ((lt >> 2) & 1) * half-image stride (X and G differ) + r * V3_LT * 4
         const int xh0 = lds0 + ((lt >> 2) & 1) * V3_XH, gh0 = lds0 + ((lt >> 2) & 1) * V3_GH;
-#else
-        const int lds0 = lt * 8;
-#endif
         constexpr int RL = V3_X_ROUNDS - 1;                      // last X round: only part of the threads have a slot,
         const bool live6 = RL * V3_LT + lt < V3_X_SLOTS;         // the others write a sink
-
+        // The two top rows by LDS copy: 16-byte unit u = i * V3_LT + lt -> region u / 136 (term image, channel half), byte
+        // 16 * (u % 136) of the region's two rows; source = rows V3_TH, V3_TH + 1 of the buffer being multiplied, destination =
+        // rows 0, 1 of the buffer being filled.  Threads past the last unit copy 16 bytes of the sink onto themselves.
+        int cpy[V3_CPY_ROUNDS];
+#pragma unroll
+        for (int i = 0; i < V3_CPY_ROUNDS; ++i) {
+            const int u = i * V3_LT + lt;
+            const int reg = u / (V3_ROW2 / 16), w16 = u - reg * (V3_ROW2 / 16);
+            cpy[i] = u < V3_CPY_UNITS ? (reg >> 1) * V3_XT + (reg & 1) * V3_XH + w16 * 16 : -1;
+        }
 
         f32x4 px[V3_X_ROUNDS] = {};
         f32x4 pg[V3_G_ROUNDS] = {};
@@ -221,68 +245,67 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
         static_assert(V3_NL - 1 <= 63, "vmcnt is a 6-bit counter");
 
         struct TileAt { i32x4 xrs, grs; int xorg, gorg, x0; };
-        auto tile_at = [&](int k) {        // descriptors and origin offsets of this workgroup's k-th tile (empty past the end)
+        auto tile_at = [&](int k) {        // descriptors and origin offsets of this workgroup's k-th item (empty past the end)
             const bool live = k < my_tiles;
-            const int t = part + k * P.nparts;
-            const int tx = t % P.tilesX;
-            const int t2 = t / P.tilesX;
-            const int ty = t2 % tilesY;
-            const int b = live ? t2 / tilesY : 0;
+            const int q = q0 + k;
+            const int sidx = q / SE;
+            const int ty = q - sidx * SE - 1;                  // -1: the warm-up item of a strip (no G)
+            const int strip = strip0 + sidx;
+            const int b = live ? strip / P.tilesX : 0;
+            const int tx = strip - (strip / P.tilesX) * P.tilesX;
             TileAt a;
             a.x0 = tx * TILE_W;
             const int y0 = ty * V3_TH;
             a.xrs = make_rsrc(reinterpret_cast<unsigned long long>(xp.p + (long long)b * xp.bs), live ? x_bytes : 0u);
-            a.grs = make_rsrc(reinterpret_cast<unsigned long long>(gp.p + (long long)b * gp.bs), live ? g_bytes : 0u);
-            a.xorg = ((y0 - 1) * xp.rs + (a.x0 - 1) * xp.ps) * 4;    // rows above / below the image fall outside [0, bytes): zeros
-            a.gorg = (y0 * gp.rs + a.x0 * gp.ps) * 4;
+            a.grs = make_rsrc(reinterpret_cast<unsigned long long>(gp.p + (long long)b * gp.bs), (live && ty >= 0) ? g_bytes : 0u);
+            a.xorg = ((y0 + 1) * xp.rs + (a.x0 - 1) * xp.ps) * 4;    // rows above / below the image fall outside [0, bytes): zeros
+            a.gorg = (y0 * gp.rs + a.x0 * gp.ps) * 4;                 // (the warm-up item's G offsets are negative AND its descriptor is empty)
             return a;
         };
         // columns left / right of the image would alias the neighbouring row: those lanes get the failing offset
         auto x_off = [&](int r, const TileAt& a) { return ((unsigned)(a.x0 - 1 + xhx[r]) < (unsigned)P.W) ? a.xorg + xrel[r] : OOR; };
         auto g_off = [&](int r, const TileAt& a) { return (a.x0 + ggx[r] < P.W) ? a.gorg + grel[r] : OOR; };
-#if defined(XSD_DIAG) && defined(XSD_ABL)   // timing experiments: a COMPILE-TIME constant (-DXSD_DIAG -DXSD_ABL=n builds; a run-time
-                                                  // value puts the hand-counted loads and waits under branches hipcc cannot keep exact)
-        constexpr int abl = XSD_ABL;     // 1: no split, 2: no LDS writes (results are garbage: timing experiments only)
-#else
-        constexpr int abl = 0;
-#endif
-        auto store_x = [&](int r, int buf) {
+        auto split_to = [&](const f32x4& v, float s, char* d, int term_stride) {
             u32x2 hi, lo;
-            if (abl & 1) { hi[0] = __float_as_uint(px[r][0]); hi[1] = __float_as_uint(px[r][1]); lo[0] = __float_as_uint(px[r][2]); lo[1] = __float_as_uint(px[r][3]); }
-            else split2_f16x4(px[r], sx, hi, lo);
-            const bool sink = (r == RL && !live6);
-#ifdef V3_SHAPE16
-            char* d = smem + (sink ? V3_SINK + (lt & 63) * 8 : buf + xh0 + r * (V3_LT * 4));
-#else
-            char* d = smem + (sink ? V3_SINK + (lt & 63) * 8 : buf + lds0 + r * (V3_LT * 8));
-#endif
+            if (abl & 1) { hi[0] = __float_as_uint(v[0]); hi[1] = __float_as_uint(v[1]); lo[0] = __float_as_uint(v[2]); lo[1] = __float_as_uint(v[3]); }
+            else split2_f16x4(v, s, hi, lo);
             if (abl & 2) { asm volatile("" :: "v"(hi), "v"(lo), "v"(d)); return; }   // diag: no LDS writes
             *reinterpret_cast<u32x2*>(d) = hi;
-            *reinterpret_cast<u32x2*>(d + (sink ? 512 : V3_XT)) = lo;
+            *reinterpret_cast<u32x2*>(d + term_stride) = lo;
+        };
+        auto store_x = [&](int r, int buf) {            // fetched rows: LDS rows 2 ..
+            const bool sink = (r == RL && !live6);
+            split_to(px[r], sx, smem + (sink ? V3_SINK + (lt & 63) * 8 : buf + V3_ROW2 + xh0 + r * (V3_LT * 4)), sink ? 512 : V3_XT);
         };
         auto store_g = [&](int r, int buf) {
-            u32x2 hi, lo;
-            if (abl & 1) { hi[0] = __float_as_uint(pg[r][0]); hi[1] = __float_as_uint(pg[r][1]); lo[0] = __float_as_uint(pg[r][2]); lo[1] = __float_as_uint(pg[r][3]); }
-            else split2_f16x4(pg[r], sg, hi, lo);
-#ifdef V3_SHAPE16
-            char* d = smem + buf + V3_G_OFF + gh0 + r * (V3_LT * 4);
-#else
-            char* d = smem + buf + V3_G_OFF + lds0 + r * (V3_LT * 8);
-#endif
-            if (abl & 2) { asm volatile("" :: "v"(hi), "v"(lo), "v"(d)); bsum += pg[r]; return; }
-            *reinterpret_cast<u32x2*>(d) = hi;
-            *reinterpret_cast<u32x2*>(d + V3_GT) = lo;
+            split_to(pg[r], sg, smem + buf + V3_G_OFF + gh0 + r * (V3_LT * 4), V3_GT);
             bsum += pg[r];
         };
 
-        // prologue: tile 0 into LDS buffer 0, tile 1 into the staging registers
+        // prologue: item 0 (the chunk's first tile, never a warm-up) WHOLE into LDS buffer 0 -- its two top rows through three
+        // extra rounds of loads --, item 1 into the staging registers
         {
             const TileAt a = tile_at(0);
+            f32x4 ptop[V3_TOP_ROUNDS] = {};
+#pragma unroll
+            for (int r = 0; r < V3_TOP_ROUNDS; ++r) {
+                const int slot = r * V3_LT + lt;
+                const int p = slot >> 3, c = slot & 7;
+                const int hy = p / HALO_W, hx = p - hy * HALO_W;
+                const bool ok = slot < V3_TOP_SLOTS && ((unsigned)(a.x0 - 1 + hx) < (unsigned)P.W);
+                asm_load4(ptop[r], ok ? a.xorg + ((hy - 2) * xp.rs + hx * xp.ps + c * 4) * 4 : OOR, a.xrs);
+            }
 #pragma unroll
             for (int r = 0; r < V3_X_ROUNDS; ++r) asm_load4(px[r], x_off(r, a), a.xrs);
 #pragma unroll
             for (int r = 0; r < V3_G_ROUNDS; ++r) asm_load4(pg[r], g_off(r, a), a.grs);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < V3_TOP_ROUNDS; ++r) {
+                asm volatile("" : "+v"(ptop[r]));
+                const bool sink = r * V3_LT + lt >= V3_TOP_SLOTS;
+                split_to(ptop[r], sx, smem + (sink ? V3_SINK + (lt & 63) * 8 : xh0 + r * (V3_LT * 4)), sink ? 512 : V3_XT);
+            }
 #pragma unroll
             for (int r = 0; r < V3_X_ROUNDS; ++r) { asm volatile("" : "+v"(px[r])); store_x(r, 0); }
 #pragma unroll
@@ -299,33 +322,43 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
         V3_LTICK(1);
 #pragma unroll 1
         for (int k = 0; k < my_tiles; ++k) {
-            // tile k+1: registers -> the other buffer; each register is refilled with tile k+2 right after its split
+            if (abl & 128) { lds_barrier(); continue; }
+            // item k+1: registers -> the other buffer; each register is refilled with item k+2 right after its split
             const TileAt a = tile_at(k + 2);
-            const int nb = ((k + 1) & 1) * V3_BUF;
+            const int cb = (k & 1) * V3_BUF, nb = ((k + 1) & 1) * V3_BUF;
+            // item k+1's two top rows = item k's two bottom rows (complete since the barrier that ended the previous pass)
+            f32x4 ctmp[V3_CPY_ROUNDS];
+#pragma unroll
+            for (int i = 0; i < V3_CPY_ROUNDS; ++i)
+                ctmp[i] = *reinterpret_cast<const f32x4*>(smem + (cpy[i] >= 0 ? cb + V3_TH * HALO_W * 32 + cpy[i] : V3_SINK + (lt & 63) * 16));
 #pragma unroll
             for (int r = 0; r < V3_X_ROUNDS; ++r) {
 #ifdef XSD_DIAG
                 const unsigned long long w0_ = __builtin_readcyclecounter();
 #endif
-                asm_wait(px[r]);
+                if (!(abl & 4)) asm_wait(px[r]);
 #ifdef XSD_DIAG
                 wst += __builtin_readcyclecounter() - w0_;
 #endif
                 store_x(r, nb);
-                asm_load4(px[r], x_off(r, a), a.xrs);
+                if (!(abl & 4)) asm_load4(px[r], x_off(r, a), a.xrs);
                 __builtin_amdgcn_sched_barrier(0);   // one round at a time, in order (the wait counts depend on it)
             }
+#pragma unroll
+            for (int i = 0; i < V3_CPY_ROUNDS; ++i)
+                *reinterpret_cast<f32x4*>(smem + (cpy[i] >= 0 ? nb + cpy[i] : V3_SINK + (lt & 63) * 16)) = ctmp[i];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < V3_G_ROUNDS; ++r) {
 #ifdef XSD_DIAG
                 const unsigned long long w1_ = __builtin_readcyclecounter();
 #endif
-                asm_wait(pg[r]);
+                if (!(abl & 4)) asm_wait(pg[r]);
 #ifdef XSD_DIAG
                 wst += __builtin_readcyclecounter() - w1_;
 #endif
                 store_g(r, nb);
-                asm_load4(pg[r], g_off(r, a), a.grs);
+                if (!(abl & 4)) asm_load4(pg[r], g_off(r, a), a.grs);
                 __builtin_amdgcn_sched_barrier(0);
             }
             V3_LTICK(0);
@@ -346,21 +379,13 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
 #pragma unroll
         for (int k = 0; k < NU; ++k)
 #pragma unroll
-#ifdef V3_SHAPE16
             for (int i = 0; i < 16; ++i) acc[k][i >> 3][(i >> 2) & 1][i & 3] = 0.f;
-#else
-            for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
-#endif
         // per-lane base of the transposing reads: lane i of a 16-lane group addresses block row q = i>>2 (pixel) and
         // columns 4p..4p+3 (p = i&3) of channel group (lane>>4)&1; the lane half h selects pixels +8.
         const int i16 = lane & 15;
         // 16x16x32: lane group g = lane >> 4 supplies k = 8g .. 8g+7, which this kernel maps to the pixels 4g .. 4g+3 (first
         // read) and 16 + 4g .. 16 + 4g+3 (second read) of the 32-pixel row -- any k <-> pixel map serves, X and G use the same
-#ifdef V3_SHAPE16
         const int lane_off = (4 * (lane >> 4) + (i16 >> 2)) * 32 + (i16 & 3) * 8;
-#else
-        const int lane_off = (8 * h + (i16 >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (i16 & 3) * 8;
-#endif
         lds_barrier();                                                                     // (P)
         V3_TICK(1);
         // one instantiation per wave (the unit table is a compile-time function of the wave index)
@@ -375,7 +400,6 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             for (int k = 0; k < my_tiles; ++k) {
                 const char* xb = smem + (k & 1) * V3_BUF + lane_off;                       // + term image + half image + (halo row * 34 + dx) * 32
                 const char* gb = smem + (k & 1) * V3_BUF + V3_G_OFF + lane_off + g_img;    // + half image + row * 32 * 32
-#ifdef V3_SHAPE16
                 // 2 * V3_TH steps (tile row r = st >> 1, input-channel half a = st & 1) of 32 pixels; per unit and step two MFMAs (the
                 // two output-channel halves).  Halo row h's fragment of the wave's column lives in xr[h & 3][a] from the step
                 // that requests it (two rows ahead of its first use) until tile row h has used it as its dy = 0 operand; the G
@@ -384,6 +408,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
                 f16x8 xr[4][2], xs[2], gf[2][2];      // gf[row parity][output-channel half]
                 auto frag16 = [&](const char* base, int off) {
                     typedef __attribute__((address_space(3))) s16x4* lds_p;
+                    if (abl & 256) { f16x8 z; asm volatile("" : "=v"(z)); return z; }
                     const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off));
                     const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off + 16 * 32));
                     s16x8 v;
@@ -398,6 +423,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
                 };
                 auto load_single = [&](int st) { xs[st & 1] = frag16(xb, V3_XT + (st & 1) * V3_XH + (((st >> 1) + w) * HALO_W + 2) * 32); };
                 // what step 0 and 1 need: halo rows 0, 1, 2 in both halves, G row 0, the single's first fragment
+                if (abl & 64) { V3_TICK(0); lds_barrier(); V3_TICK(1); continue; }
                 load_g(0);
 #pragma unroll
                 for (int a = 0; a < 2; ++a) { load_row(0, a); load_row(1, a); load_row(2, a); }
@@ -415,48 +441,16 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
                     for (int q = 0; q < 3; ++q)
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
-                            acc[q][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xr[(r + q) & 3][a], gf[r & 1][b], acc[q][a][b], 0, 0, 0);
+                            if (abl & 32) asm volatile("" :: "v"(xr[(r + q) & 3][a]), "v"(gf[r & 1][b]));
+                            else acc[q][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xr[(r + q) & 3][a], gf[r & 1][b], acc[q][a][b], 0, 0, 0);
                     if (single) {
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
-                            acc[3][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xs[st & 1], gf[r & 1][b], acc[3][a][b], 0, 0, 0);
+                            if (abl & 32) asm volatile("" :: "v"(xs[st & 1]), "v"(gf[r & 1][b]));
+                            else acc[3][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xs[st & 1], gf[r & 1][b], acc[3][a][b], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#else
-                // -DV3_SHAPE32: 2 * V3_TH steps (tile row r = st >> 1, pixel half mf = st & 1) of 16 pixels, ONE 32x32x16 MFMA per unit and
-                // step; the same column ring (halo row h of the wave's column in xr[h & 3][mf]), G fragment per step
-                f16x8 xr[4][2], xs[2], gf[2];
-                auto frag32 = [&](const char* base, int off) {     // 8 consecutive pixels (k = 8h + 0..7) of this lane's channel from a [pixel][32 x f16] image
-                    typedef __attribute__((address_space(3))) s16x4* lds_p;
-                    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off));
-                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + off + 4 * 64));
-                    s16x8 v;
-                    v[0] = lo4[0]; v[1] = lo4[1]; v[2] = lo4[2]; v[3] = lo4[3];
-                    v[4] = hi4[0]; v[5] = hi4[1]; v[6] = hi4[2]; v[7] = hi4[3];
-                    return __builtin_bit_cast(f16x8, v);
-                };
-                auto load_row = [&](int hrow, int mf) { xr[hrow & 3][mf] = frag32(xb, x_img + (hrow * HALO_W + dxT + 16 * mf) * 64); };
-                auto load_g = [&](int st) { gf[st & 1] = frag32(gb, ((st >> 1) * TILE_W + 16 * (st & 1)) * 64); };
-                auto load_single = [&](int st) { xs[st & 1] = frag32(xb, V3_XT + (((st >> 1) + w) * HALO_W + 2 + 16 * (st & 1)) * 64); };
-                load_g(0);
-#pragma unroll
-                for (int mf = 0; mf < 2; ++mf) { load_row(0, mf); load_row(1, mf); load_row(2, mf); }
-                if (single) load_single(0);
-#pragma unroll
-                for (int st = 0; st < 2 * V3_TH; ++st) {
-                    const int r = st >> 1, mf = st & 1;
-                    if (r + 3 < V3_TH + 2) load_row(r + 3, mf);
-                    if (st + 1 < 2 * V3_TH) load_g(st + 1);
-                    if (single && st + 1 < 2 * V3_TH) load_single(st + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xr[(r + q) & 3][mf], gf[st & 1], acc[q], 0, 0, 0);
-                    if (single) acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xs[st & 1], gf[st & 1], acc[3], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#endif
                 V3_TICK(0);
                 lds_barrier();
                 V3_TICK(1);
@@ -489,17 +483,10 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             const int u = v3_unit(wv, q);            // slab = unit number 9 * product + tap (-1: this wave has no fourth unit)
             if (u >= 0) {
 #pragma unroll
-#ifdef V3_SHAPE16
                 for (int i = 0; i < 16; ++i) {      // tile (a, b), register t: input channel 16a + 4 (lane >> 4) + t, output channel 16b + (lane & 15)
                     const int a = i >> 3, b = (i >> 2) & 1, t = i & 3;
                     red[u * 1024 + (16 * a + 4 * (lane >> 4) + t) * 32 + 16 * b + (lane & 15)] = acc[q][a][b][t];
                 }
-#else
-                for (int i = 0; i < 16; ++i) {
-                    const int ci = (i & 3) + 8 * (i >> 2) + 4 * h;
-                    red[u * 1024 + ci * 32 + l31] = acc[q][i];
-                }
-#endif
             }
         }
     }
