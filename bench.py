@@ -106,6 +106,69 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA peak (MI355X_MICROARCH
 HBM_PEAK_GBPS = 8000.0
 
 
+class PowerWatch:
+    """Samples the package power and the shader clock of the busiest amdgpu device from sysfs (hwmon power1_average / power1_input,
+    freq1_input, power1_cap) while the timed region runs -- a reader thread, no subprocess, nothing on the GPU.  The train step
+    of this engine runs AT the package power cap: the clock the chip holds, and with it every kernel's
+    milliseconds, is set by the energy a tile costs, so the line reports what was drawn beside what was computed.  Returns None
+    where the files are not readable (no GPU, other driver)."""
+
+    def __init__(self, period=0.1):
+        import glob
+        import threading
+        self.period = period
+        self.devs = []
+        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            pw = next((os.path.join(h, f) for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, f))), None)
+            if pw:
+                self.devs.append({"hwmon": h, "power": pw, "freq": os.path.join(h, "freq1_input"), "cap": os.path.join(h, "power1_cap"), "w": [], "mhz": []})
+        self._stop = threading.Event()
+        self._thr = threading.Thread(target=self._run, daemon=True) if self.devs else None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            for d in self.devs:
+                w = self._read(d["power"])
+                if w is not None:
+                    d["w"].append(w * 1e-6)
+                f = self._read(d["freq"])
+                if f is not None:
+                    d["mhz"].append(f * 1e-6)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self._thr:
+            self._thr.start()
+        return self
+
+    def __exit__(self, *a):
+        if self._thr:
+            self._stop.set()
+            self._thr.join()
+
+    def summary(self):
+        best = None
+        for d in self.devs:
+            w = d["w"][len(d["w"]) // 5:]            # the first fifth is the ramp from idle
+            if len(w) >= 3 and (best is None or sum(w) / len(w) > best["avg_w"]):
+                mhz = d["mhz"][len(d["mhz"]) // 5:]
+                cap = self._read(d["cap"])
+                best = {"avg_w": round(sum(w) / len(w), 1), "max_w": round(max(w), 1), "cap_w": round(cap * 1e-6, 1) if cap else None,
+                        "sclk_mhz": round(sum(mhz) / len(mhz), 0) if mhz else None, "samples": len(w),
+                        "source": "sysfs hwmon of the busiest amdgpu device, sampled every %.0f ms over the timed region (first fifth dropped)" % (1e3 * self.period)}
+        if best and best["cap_w"]:
+            best["frac_of_cap"] = round(best["avg_w"] / best["cap_w"], 3)
+        return best
+
+
 def pmc_traffic(math: str, batch: int, klass: str):
     """HBM bytes per launch from the committed PMC passes (tools/traffic.sh -> profiles/rNN_traffic_<math>.json, newest round
     first), valid only for the workload/batch they were collected on.  Returns (bytes, file) or (None, None): the figure is
@@ -339,7 +402,9 @@ def main():
             eng.profile_enable(False)
         return dt, prof
 
-    dt, prof = timed(args.warmup, args.steps, not args.no_profile)
+    with PowerWatch() as pwatch:
+        dt, prof = timed(args.warmup, args.steps, not args.no_profile)
+    power = pwatch.summary() if (rank == 0 and world == 1) else None
 
     replicas_identical = None
     if dp and train:     # DDP invariant, checked outside the timed region: every rank holds bit-identical parameters
@@ -364,10 +429,13 @@ def main():
         with torch.no_grad():
             y_x = model(x[:2])
         err = float((y_x - y_head).abs().max())
-        dte, profe = timed(args.warmup, args.steps, not args.no_profile)
+        with PowerWatch() as pwx:
+            dte, profe = timed(args.warmup, args.steps, not args.no_profile)
         extra = {"math": xm, "dtype": MATHS[xm][0], "value": B * world * args.steps / dte, "unit": "tiles/s",
                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dte / args.steps,
                  "max_abs_output_diff_vs_" + args.math: err, "note": "not the headline: the strict mode, reported for comparison"}
+        if pwx.summary() is not None:
+            extra["power"] = pwx.summary()
         if profe is not None and profe[0]["launches"] > 0:
             extra["roofline"] = roofline_block(xm, profe, B, kind, train, world, B * world * args.steps / dte, NF == 32)
         model.set_math(args.math)
@@ -394,6 +462,8 @@ def main():
             out["replicas_identical"] = replicas_identical
         if prof is not None and prof[0]["launches"] > 0:
             out["roofline"] = roofline_block(args.math, prof, B, kind, train, world, tiles / dt, NF == 32)
+        if power is not None:
+            out["power"] = power
         if extra is not None:
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline and NF == 32:

@@ -177,6 +177,7 @@ static unsigned short f2h(float f)
 int main(int argc, char** argv)
 {
     const int iters = argc > 1 ? atoi(argv[1]) : 20000;
+    const int only = argc > 2 ? atoi(argv[2]) : -1;      // 0 / 1: that shape only (for a power reading: tools/power_of.py)
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int G = prop.multiProcessorCount;
@@ -205,6 +206,7 @@ int main(int argc, char** argv)
     printf("conv_shape_probe: %d CUs, %d half-steps per launch; per wave and half-step: A = 54 x 32x32x16 + 42 ds_read_b128, B = 120 x 16x16x32 + 60 ds_read_b128\n", G, iters);
     for (int rep = 0; rep < 3; ++rep)
         for (int shape = 0; shape < 2; ++shape) {
+            if (only >= 0 && shape != only) continue;
             for (int pass = 0; pass < 2; ++pass) {          // pass 0 warms the clock governor up, pass 1 is reported
                 hipEventRecord(e0, 0);
                 if (shape == 0) hipLaunchKernelGGL(probe_kernel<0>, dim3(G), dim3(512), LDS_BYTES, 0, d_src, d_out, d_clk, iters);

@@ -320,11 +320,49 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
         }
         lds_barrier();                                                                     // (P)
         V3_LTICK(1);
+        // round i of a pass: X round i for i < V3_X_ROUNDS, then the G rounds
+        auto rreg = [&](int i) -> f32x4& { return i < V3_X_ROUNDS ? px[i] : pg[i - V3_X_ROUNDS]; };
+        auto rdst = [&](int i, int buf) -> char* {
+            if (i < V3_X_ROUNDS) return smem + ((i == RL && !live6) ? V3_SINK + (lt & 63) * 8 : buf + V3_ROW2 + xh0 + i * (V3_LT * 4));
+            return smem + buf + V3_G_OFF + gh0 + (i - V3_X_ROUNDS) * (V3_LT * 4);
+        };
+        auto rstride = [&](int i) { return i < V3_X_ROUNDS ? ((i == RL && !live6) ? 512 : V3_XT) : V3_GT; };
+        // The cursor of the item whose loads a pass issues (item k + 2), advanced by compare-and-select instead of decoded by two
+        // integer divisions per pass; the lanes' column validity is a property of the STRIP, so the offsets with the failing
+        // value folded in are rebuilt only when the cursor enters a strip (a wave-uniform branch that touches no load register).
+        struct Cur3 { int ty, tx, b; };
+        Cur3 c2;
+        {
+            const int q = q0 + 2, sidx = q / SE, strip = strip0 + sidx;
+            c2.ty = q - sidx * SE - 1; c2.b = strip / P.tilesX; c2.tx = strip - c2.b * P.tilesX;
+        }
+        int xcol[V3_X_ROUNDS], gcol[V3_G_ROUNDS];
+        auto strip_offsets = [&](int tx) {
+            const int x0 = tx * TILE_W;
+#pragma unroll
+            for (int r = 0; r < V3_X_ROUNDS; ++r) xcol[r] = ((unsigned)(x0 - 1 + xhx[r]) < (unsigned)P.W) ? xrel[r] : OOR;
+#pragma unroll
+            for (int r = 0; r < V3_G_ROUNDS; ++r) gcol[r] = (x0 + ggx[r] < P.W) ? grel[r] : OOR;
+        };
+        strip_offsets(c2.tx);
 #pragma unroll 1
         for (int k = 0; k < my_tiles; ++k) {
             if (abl & 128) { lds_barrier(); continue; }
             // item k+1: registers -> the other buffer; each register is refilled with item k+2 right after its split
-            const TileAt a = tile_at(k + 2);
+            TileAt a;
+            {
+                const bool live = k + 2 < my_tiles;
+                if (c2.ty == -1) strip_offsets(c2.tx);
+                a.x0 = c2.tx * TILE_W;
+                const int y0 = c2.ty * V3_TH;
+                a.xrs = make_rsrc(reinterpret_cast<unsigned long long>(xp.p + (long long)c2.b * xp.bs), live ? x_bytes : 0u);
+                a.grs = make_rsrc(reinterpret_cast<unsigned long long>(gp.p + (long long)c2.b * gp.bs), (live && c2.ty >= 0) ? g_bytes : 0u);
+                a.xorg = ((y0 + 1) * xp.rs + (a.x0 - 1) * xp.ps) * 4;
+                a.gorg = (y0 * gp.rs + a.x0 * gp.ps) * 4;
+                if (++c2.ty == tilesY) { c2.ty = -1; if (++c2.tx == P.tilesX) { c2.tx = 0; ++c2.b; } }
+            }
+            auto roff = [&](int i) { return i < V3_X_ROUNDS ? a.xorg + xcol[i] : a.gorg + gcol[i - V3_X_ROUNDS]; };   // (0x80000000 + a small origin still fails the range check)
+            auto rrs = [&](int i) -> const i32x4& { return i < V3_X_ROUNDS ? a.xrs : a.grs; };
             const int cb = (k & 1) * V3_BUF, nb = ((k + 1) & 1) * V3_BUF;
             // item k+1's two top rows = item k's two bottom rows (complete since the barrier that ended the previous pass)
             f32x4 ctmp[V3_CPY_ROUNDS];
@@ -332,34 +370,23 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
             for (int i = 0; i < V3_CPY_ROUNDS; ++i)
                 ctmp[i] = *reinterpret_cast<const f32x4*>(smem + (cpy[i] >= 0 ? cb + V3_TH * HALO_W * 32 + cpy[i] : V3_SINK + (lt & 63) * 16));
 #pragma unroll
-            for (int r = 0; r < V3_X_ROUNDS; ++r) {
+            for (int i = 0; i < V3_NL; ++i) {
 #ifdef XSD_DIAG
                 const unsigned long long w0_ = __builtin_readcyclecounter();
 #endif
-                if (!(abl & 4)) asm_wait(px[r]);
+                if (!(abl & 4)) asm_wait(rreg(i));
 #ifdef XSD_DIAG
                 wst += __builtin_readcyclecounter() - w0_;
 #endif
-                store_x(r, nb);
-                if (!(abl & 4)) asm_load4(px[r], x_off(r, a), a.xrs);
+                split_to(rreg(i), i < V3_X_ROUNDS ? sx : sg, rdst(i, nb), rstride(i));
+                if (i >= V3_X_ROUNDS) bsum += rreg(i);
+                if (!(abl & 4)) asm_load4(rreg(i), roff(i), rrs(i));
+                if (i == V3_X_ROUNDS - 1) {
+#pragma unroll
+                    for (int c = 0; c < V3_CPY_ROUNDS; ++c)
+                        *reinterpret_cast<f32x4*>(smem + (cpy[c] >= 0 ? nb + cpy[c] : V3_SINK + (lt & 63) * 16)) = ctmp[c];
+                }
                 __builtin_amdgcn_sched_barrier(0);   // one round at a time, in order (the wait counts depend on it)
-            }
-#pragma unroll
-            for (int i = 0; i < V3_CPY_ROUNDS; ++i)
-                *reinterpret_cast<f32x4*>(smem + (cpy[i] >= 0 ? nb + cpy[i] : V3_SINK + (lt & 63) * 16)) = ctmp[i];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < V3_G_ROUNDS; ++r) {
-#ifdef XSD_DIAG
-                const unsigned long long w1_ = __builtin_readcyclecounter();
-#endif
-                if (!(abl & 4)) asm_wait(pg[r]);
-#ifdef XSD_DIAG
-                wst += __builtin_readcyclecounter() - w1_;
-#endif
-                store_g(r, nb);
-                if (!(abl & 4)) asm_load4(pg[r], g_off(r, a), a.grs);
-                __builtin_amdgcn_sched_barrier(0);
             }
             V3_LTICK(0);
             lds_barrier();
