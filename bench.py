@@ -113,12 +113,12 @@ class PowerWatch:
     milliseconds, is set by the energy a tile costs, so the line reports what was drawn beside what was computed.  Returns None
     where the files are not readable (no GPU, other driver)."""
 
-    def __init__(self, period=0.1):
+    def __init__(self, period=0.1, root="/sys/class/drm"):
         import glob
         import threading
         self.period = period
         self.devs = []
-        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        for h in sorted(glob.glob(os.path.join(root, "card*/device/hwmon/hwmon*"))):
             pw = next((os.path.join(h, f) for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, f))), None)
             if pw:
                 self.devs.append({"hwmon": h, "power": pw, "freq": os.path.join(h, "freq1_input"), "cap": os.path.join(h, "power1_cap"), "w": [], "mhz": []})

@@ -121,6 +121,26 @@ def test_bench_one_rank_over_rccl_with_the_reduce_path_forced():
     assert d["replicas_identical"] is True and d["value"] > 0
 
 
+def test_bench_line_reports_package_power_and_clock():
+    """The default bench line carries what the device drew over the timed region (sysfs hwmon, bench.PowerWatch): the train
+    step of this engine runs at the package power cap, so the rate is read beside the watts and the clock."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "XSD_DIST_BACKEND", "XSD_FORCE_DP"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "3", "--no-extra", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0, out[-3000:]
+    d = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    pw = d.get("power")
+    if pw is None:
+        pytest.skip("no readable amdgpu hwmon files on this box")
+    assert pw["cap_w"] and 0.5 < pw["frac_of_cap"] <= 1.05, pw      # measured: 0.93 (short run, ramp included) ... 0.999
+    assert 500 <= pw["sclk_mhz"] <= 2600 and pw["samples"] >= 3, pw
+
+
 def test_train_driver_one_rank_over_rccl(tmp_path):
     """train.py with a one-rank RCCL group (XSD_FORCE_DP=1): the trainer's exchange plus the validation epoch's state
     reduction (EpochState.sync: device float64 tensors, SUM / MIN / MAX) over the nccl backend."""
