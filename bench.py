@@ -166,6 +166,11 @@ class PowerWatch:
                         "source": "sysfs hwmon of the busiest amdgpu device, sampled every %.0f ms over the timed region (first fifth dropped)" % (1e3 * self.period)}
         if best and best["cap_w"]:
             best["frac_of_cap"] = round(best["avg_w"] / best["cap_w"], 3)
+        if best:      # a multi-GPU run: every device that worked (rank 0 reads them all), busiest first
+            others = sorted((round(sum(d["w"][len(d["w"]) // 5:]) / max(1, len(d["w"][len(d["w"]) // 5:])), 1) for d in self.devs if len(d["w"]) >= 3), reverse=True)
+            busy = [w for w in others if w > 0.5 * best["avg_w"]]
+            if len(busy) > 1:
+                best["busy_devices_avg_w"] = busy
         return best
 
 
@@ -404,7 +409,7 @@ def main():
 
     with PowerWatch() as pwatch:
         dt, prof = timed(args.warmup, args.steps, not args.no_profile)
-    power = pwatch.summary() if (rank == 0 and world == 1) else None
+    power = pwatch.summary() if rank == 0 else None
 
     replicas_identical = None
     if dp and train:     # DDP invariant, checked outside the timed region: every rank holds bit-identical parameters

@@ -34,3 +34,14 @@ def test_power_watch_without_devices_reports_nothing(tmp_path):
     with bench.PowerWatch(0.01, root=str(tmp_path)) as pw:
         time.sleep(0.05)
     assert pw.summary() is None
+
+
+def test_power_watch_lists_every_working_device_of_a_multi_gpu_run(tmp_path):
+    import bench
+    _fake_card(str(tmp_path), "card0", 240, 100)
+    _fake_card(str(tmp_path), "card1", 1390, 1640)
+    _fake_card(str(tmp_path), "card2", 1396, 1650)
+    with bench.PowerWatch(0.01, root=str(tmp_path)) as pw:
+        time.sleep(0.3)
+    s = pw.summary()
+    assert s["busy_devices_avg_w"] == [1396.0, 1390.0] and abs(s["avg_w"] - 1396.0) < 0.5
