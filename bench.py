@@ -107,21 +107,31 @@ HBM_PEAK_GBPS = 8000.0
 
 
 class PowerWatch:
-    """Samples the package power and the shader clock of the busiest amdgpu device from sysfs (hwmon power1_average / power1_input,
-    freq1_input, power1_cap) while the timed region runs -- a reader thread, no subprocess, nothing on the GPU.  The train step
-    of this engine runs AT the package power cap: the clock the chip holds, and with it every kernel's
-    milliseconds, is set by the energy a tile costs, so the line reports what was drawn beside what was computed.  Returns None
-    where the files are not readable (no GPU, other driver)."""
+    """Samples the package power and the shader clock of THIS job's amdgpu devices from sysfs (hwmon power1_average / power1_input,
+    freq1_input, power1_cap) while the timed region runs -- a reader thread, no subprocess, nothing on the GPU.  `pci` names the
+    devices by PCI address prefix ("0000:05:00", from torch's device properties): a GPU box shows the hwmon files of every card
+    of its host, other tenants' included.  Without it (tools, tests) the busiest device is reported and the source says so.
+    The train step of this engine runs AT the package power cap: the clock the chip holds, and with it every
+    kernel's milliseconds, is set by the energy a tile costs, so the line reports what was drawn beside what was computed.
+    Returns None where the files are not readable (no GPU, other driver)."""
 
-    def __init__(self, period=0.1, root="/sys/class/drm"):
+    def __init__(self, period=0.1, root="/sys/class/drm", pci=None):
         import glob
         import threading
         self.period = period
         self.devs = []
+        self.matched = False
+        found = []
         for h in sorted(glob.glob(os.path.join(root, "card*/device/hwmon/hwmon*"))):
             pw = next((os.path.join(h, f) for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, f))), None)
             if pw:
-                self.devs.append({"hwmon": h, "power": pw, "freq": os.path.join(h, "freq1_input"), "cap": os.path.join(h, "power1_cap"), "w": [], "mhz": []})
+                addr = os.path.basename(os.path.realpath(os.path.dirname(os.path.dirname(h))))       # .../0000:05:00.0
+                found.append({"hwmon": h, "pci": addr, "power": pw, "freq": os.path.join(h, "freq1_input"), "cap": os.path.join(h, "power1_cap"), "w": [], "mhz": []})
+        if pci:
+            mine = [d for d in found if any(d["pci"].lower().startswith(p.lower()) for p in pci)]
+            if mine:
+                found, self.matched = mine, True
+        self.devs = found
         self._stop = threading.Event()
         self._thr = threading.Thread(target=self._run, daemon=True) if self.devs else None
 
@@ -156,22 +166,34 @@ class PowerWatch:
 
     def summary(self):
         best = None
+        avgs = []
         for d in self.devs:
             w = d["w"][len(d["w"]) // 5:]            # the first fifth is the ramp from idle
-            if len(w) >= 3 and (best is None or sum(w) / len(w) > best["avg_w"]):
+            if len(w) < 3:
+                continue
+            avgs.append(round(sum(w) / len(w), 1))
+            if best is None or sum(w) / len(w) > best["avg_w"]:
                 mhz = d["mhz"][len(d["mhz"]) // 5:]
                 cap = self._read(d["cap"])
                 best = {"avg_w": round(sum(w) / len(w), 1), "max_w": round(max(w), 1), "cap_w": round(cap * 1e-6, 1) if cap else None,
-                        "sclk_mhz": round(sum(mhz) / len(mhz), 0) if mhz else None, "samples": len(w),
-                        "source": "sysfs hwmon of the busiest amdgpu device, sampled every %.0f ms over the timed region (first fifth dropped)" % (1e3 * self.period)}
+                        "sclk_mhz": round(sum(mhz) / len(mhz), 0) if mhz else None, "samples": len(w), "pci": d["pci"],
+                        "source": "sysfs hwmon of %s, sampled every %.0f ms over the timed region (first fifth dropped)" %
+                                  ("this job's device(s), by PCI address" if self.matched else "the BUSIEST amdgpu device of the host (not matched to this job)", 1e3 * self.period)}
         if best and best["cap_w"]:
             best["frac_of_cap"] = round(best["avg_w"] / best["cap_w"], 3)
-        if best:      # a multi-GPU run: every device that worked (rank 0 reads them all), busiest first
-            others = sorted((round(sum(d["w"][len(d["w"]) // 5:]) / max(1, len(d["w"][len(d["w"]) // 5:])), 1) for d in self.devs if len(d["w"]) >= 3), reverse=True)
-            busy = [w for w in others if w > 0.5 * best["avg_w"]]
-            if len(busy) > 1:
-                best["busy_devices_avg_w"] = busy
+        if best and self.matched and len(avgs) > 1:      # a multi-GPU run: every rank's device (rank 0 reads them all), busiest first
+            best["devices_avg_w"] = sorted(avgs, reverse=True)
         return best
+
+
+def device_pci(dev=0):
+    """PCI address prefix of a torch device ("0000:05:00"), or None"""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(dev)
+        return "%04x:%02x:%02x" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except Exception:
+        return None
 
 
 def pmc_traffic(math: str, batch: int, klass: str):
@@ -407,7 +429,13 @@ def main():
             eng.profile_enable(False)
         return dt, prof
 
-    with PowerWatch() as pwatch:
+    my_pci = device_pci(dev.index if hasattr(dev, "index") and dev.index is not None else 0)
+    pcis = [my_pci]
+    if dp:      # rank 0 reads every rank's device
+        pcis = [None] * world
+        dist.all_gather_object(pcis, my_pci)
+    pcis = [p for p in pcis if p] or None
+    with PowerWatch(pci=pcis) as pwatch:
         dt, prof = timed(args.warmup, args.steps, not args.no_profile)
     power = pwatch.summary() if rank == 0 else None
 
@@ -434,7 +462,7 @@ def main():
         with torch.no_grad():
             y_x = model(x[:2])
         err = float((y_x - y_head).abs().max())
-        with PowerWatch() as pwx:
+        with PowerWatch(pci=pcis) as pwx:
             dte, profe = timed(args.warmup, args.steps, not args.no_profile)
         extra = {"math": xm, "dtype": MATHS[xm][0], "value": B * world * args.steps / dte, "unit": "tiles/s",
                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dte / args.steps,

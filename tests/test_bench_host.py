@@ -7,13 +7,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def _fake_card(root, name, watts, mhz, cap=1400):
-    h = os.path.join(root, name, "device", "hwmon", "hwmon0")
+def _fake_card(root, name, watts, mhz, cap=1400, pci=None):
+    """card<N>/device is a symlink to the PCI device directory, as in sysfs"""
+    pci = pci or ("0000:%02x:00.0" % (int(name[4:]) + 5))
+    devdir = os.path.join(root, "_pci", pci)
+    h = os.path.join(devdir, "hwmon", "hwmon0")
     os.makedirs(h)
+    os.makedirs(os.path.join(root, name))
+    os.symlink(devdir, os.path.join(root, name, "device"))
     for f, v in (("power1_input", int(watts * 1e6)), ("freq1_input", int(mhz * 1e6)), ("power1_cap", int(cap * 1e6))):
         with open(os.path.join(h, f), "w") as fh:
             fh.write("%d\n" % v)
-    return h
+    return pci
 
 
 def test_power_watch_reads_the_busiest_device(tmp_path):
@@ -36,12 +41,22 @@ def test_power_watch_without_devices_reports_nothing(tmp_path):
     assert pw.summary() is None
 
 
-def test_power_watch_lists_every_working_device_of_a_multi_gpu_run(tmp_path):
+def test_power_watch_reports_this_jobs_devices_by_pci_address(tmp_path):
+    """a GPU box shows the hwmon files of every card of its host: the job's own devices are picked by PCI address (another
+    tenant's busier card is ignored), and a multi-GPU run lists every rank's device"""
     import bench
-    _fake_card(str(tmp_path), "card0", 240, 100)
-    _fake_card(str(tmp_path), "card1", 1390, 1640)
-    _fake_card(str(tmp_path), "card2", 1396, 1650)
-    with bench.PowerWatch(0.01, root=str(tmp_path)) as pw:
+    _fake_card(str(tmp_path), "card0", 1399, 1700)                     # somebody else's
+    a = _fake_card(str(tmp_path), "card1", 1390, 1640)
+    b = _fake_card(str(tmp_path), "card2", 1396, 1650)
+    with bench.PowerWatch(0.01, root=str(tmp_path), pci=[a[:10]]) as pw:
         time.sleep(0.3)
     s = pw.summary()
-    assert s["busy_devices_avg_w"] == [1396.0, 1390.0] and abs(s["avg_w"] - 1396.0) < 0.5
+    assert s["pci"] == a and abs(s["avg_w"] - 1390.0) < 0.5 and "this job" in s["source"] and "devices_avg_w" not in s
+    with bench.PowerWatch(0.01, root=str(tmp_path), pci=[a[:10], b[:10]]) as pw:
+        time.sleep(0.3)
+    s = pw.summary()
+    assert s["devices_avg_w"] == [1396.0, 1390.0] and s["pci"] == b
+    with bench.PowerWatch(0.01, root=str(tmp_path), pci=["0000:7f:00"]) as pw:     # no match: falls back to the busiest, and says so
+        time.sleep(0.3)
+    s = pw.summary()
+    assert abs(s["avg_w"] - 1399.0) < 0.5 and "BUSIEST" in s["source"]

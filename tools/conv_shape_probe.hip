@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <random>
 #include <vector>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -125,15 +126,15 @@ __global__ __launch_bounds__(512) void probe_kernel(const unsigned int* __restri
 #pragma unroll
                 for (int t = 0; t < 2; ++t) a[p][t] = *reinterpret_cast<const f16x8*>(xc + t * XT + xoff[j][p] + r * 1024);
         };
-#pragma unroll 1
-        for (int it = 0; it < iters; ++it) {
+        auto half_step = [&](auto NSV) {
+            constexpr int NS = decltype(NSV)::value;       // 10: five K-steps (tap pairs + the half-empty ninth); 8: four
             f16x8 xf[2][2][2], wf[2][2][2];
             load_w(0, wf[0]);
             load_x(0, 0, xf[0]);
 #pragma unroll
-            for (int s = 0; s < 10; ++s) {
+            for (int s = 0; s < NS; ++s) {
                 const int j = s >> 1, r = s & 1;
-                if (s + 1 < 10) {
+                if (s + 1 < NS) {
                     const int j2 = (s + 1) >> 1, r2 = (s + 1) & 1;
                     load_x(j2, r2, xf[(s + 1) & 1]);
                     if (r2 == 0) load_w(j2, wf[j2 & 1]);
@@ -151,6 +152,13 @@ __global__ __launch_bounds__(512) void probe_kernel(const unsigned int* __restri
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+        };
+#pragma unroll 1
+        for (int it = 0; it < iters; ++it) {
+            // SHAPE 2: the zero-waste form -- the ninth tap's two channel halves as ONE K = 32 step in every other half-step (a third
+            // input buffer would keep the first half's image): four K-steps, then five = 108 MFMAs + 54 reads per half-step on average
+            if (SHAPE == 2 && !(it & 1)) half_step(std::integral_constant<int, 8>{});
+            else half_step(std::integral_constant<int, 10>{});
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -200,17 +208,19 @@ int main(int argc, char** argv)
     hipMemcpy(d_src, img.data(), LDS_BYTES, hipMemcpyHostToDevice);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<unsigned long long> clk(2 * G);
     printf("conv_shape_probe: %d CUs, %d half-steps per launch; per wave and half-step: A = 54 x 32x32x16 + 42 ds_read_b128, B = 120 x 16x16x32 + 60 ds_read_b128\n", G, iters);
     for (int rep = 0; rep < 3; ++rep)
-        for (int shape = 0; shape < 2; ++shape) {
+        for (int shape = 0; shape < 3; ++shape) {
             if (only >= 0 && shape != only) continue;
             for (int pass = 0; pass < 2; ++pass) {          // pass 0 warms the clock governor up, pass 1 is reported
                 hipEventRecord(e0, 0);
                 if (shape == 0) hipLaunchKernelGGL(probe_kernel<0>, dim3(G), dim3(512), LDS_BYTES, 0, d_src, d_out, d_clk, iters);
-                else hipLaunchKernelGGL(probe_kernel<1>, dim3(G), dim3(512), LDS_BYTES, 0, d_src, d_out, d_clk, iters);
+                else if (shape == 1) hipLaunchKernelGGL(probe_kernel<1>, dim3(G), dim3(512), LDS_BYTES, 0, d_src, d_out, d_clk, iters);
+                else hipLaunchKernelGGL(probe_kernel<2>, dim3(G), dim3(512), LDS_BYTES, 0, d_src, d_out, d_clk, iters);
                 hipEventRecord(e1, 0);
                 hipEventSynchronize(e1);
             }
@@ -220,9 +230,9 @@ int main(int argc, char** argv)
             std::vector<double> cyc(G), ghz(G);
             for (int g = 0; g < G; ++g) { cyc[g] = (double)clk[2 * g] / iters; ghz[g] = (double)clk[2 * g] / ((double)clk[2 * g + 1] * 10.0); }   // s_memrealtime: 100 MHz
             std::sort(cyc.begin(), cyc.end()); std::sort(ghz.begin(), ghz.end());
-            const double pipe = shape == 0 ? 2 * 54 * 32.0 : 2 * 120 * 16.0;      // matrix-pipe cycles per half-step and SIMD (two waves)
+            const double pipe = shape == 0 ? 2 * 54 * 32.0 : (shape == 1 ? 2 * 120 * 16.0 : 2 * 108 * 16.0);      // matrix-pipe cycles per half-step and SIMD (two waves)
             printf("  shape %c: %8.1f cycles per half-step (matrix pipe needs %.0f: %.0f %% busy), in-kernel clock %.3f GHz, %7.3f us per half-step wall\n",
-                   shape == 0 ? 'A' : 'B', cyc[G / 2], pipe, 100.0 * pipe / cyc[G / 2], ghz[G / 2], 1e3 * ms / iters);
+                   "ABC"[shape], cyc[G / 2], pipe, 100.0 * pipe / cyc[G / 2], ghz[G / 2], 1e3 * ms / iters);
         }
     return 0;
 }

@@ -5,20 +5,20 @@ O=gpurun_out/power_table.txt; : > $O
 python - >> $O 2>&1 <<'PY'
 import sys, time, torch
 sys.path.insert(0, '.')
-from bench import PowerWatch
+from bench import PowerWatch, device_pci
 n = 1 << 30                                       # 4 GiB of fp32 read + 4 GiB written per copy
 a = torch.empty(n, device='cuda'); b = torch.empty(n, device='cuda')
 a.normal_()
 for _ in range(5): b.copy_(a)
 torch.cuda.synchronize()
-with PowerWatch(0.05) as pw:
+with PowerWatch(0.05, pci=[device_pci(0)]) as pw:
     t0 = time.perf_counter()
     for _ in range(150): b.copy_(a)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 print("copy stream: %.2f TB/s (read + write)" % (150 * 2 * 4 * n / dt / 1e12), pw.summary())
 PY
-for S in 0 1; do echo "== conv MFMA-wave stream, shape $S (0: 32x32x16 shipped, 1: 16x16x32 padded)" >> $O; python tools/power_of.py tools/bin/conv_shape_probe 400000 $S >> $O 2>&1; done
+for S in 0 1 2; do echo "== conv MFMA-wave stream, shape $S (0: 32x32x16 shipped, 1: 16x16x32 as tap pairs with the half-empty ninth, 2: 16x16x32 zero-waste)" >> $O; python tools/power_of.py tools/bin/conv_shape_probe 400000 $S >> $O 2>&1; done
 for W in dn_fwd dn_train; do python bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --no-extra 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']
