@@ -16,6 +16,12 @@
 // units.  LDS fragment reads per tile row and CU: 144 -> 76 ds_read_b64_tr_b16 (the round-3 deal, units in tap order, gave
 // every unit its own fragment every step; the kernel's waves spent 26 % of their cycles stalled on LDS issue).
 // LDS: four images per buffer (X_h, X_l over the 10 x 34 halo, G_h, G_l), each [channel half][pixel][16 x f16]: 76,800 B, two buffers.
+// Round 4, second half: a workgroup walks a contiguous chunk of the tiles DOWN 32-pixel column strips; a tile's two top halo rows are
+// copied LDS -> LDS from the tile before it, the staging waves fetch and split the 8 rows below them (17 counted loads per tile and
+// thread; constants and the warm-up item below).  Measured with compile-time ablations of both roles (tools/ablate_wgrad.sh): the
+// staging waves alone need 4.66k cycles per tile, the MFMA waves alone 4.76k (3.58k of matrix work), together 5.6 - 6.0k -- the two
+// roles share one vector-issue port per SIMD, which a 16x16x32 MFMA holds 8 cycles of every 16 -- and in MILLISECONDS the kernel
+// is set by the 1400 W package power cap.
 #include <type_traits>
 #include "xsd_kernels.h"
 #include "xsd_split.h"
