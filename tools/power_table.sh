@@ -24,3 +24,12 @@ import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']
 print('$W', round(d['value'], 1), 'tiles/s', 'conv frac', round(r['frac'], 3), 'hbm GB/s (algorithmic, whole step)', round(r['whole_step']['algorithmic_GBps']), d.get('power'))" >> $O; done
 cat $O
+# (5) the train step WITHOUT its matrix instructions (experiment library: make -C xmm-superres-denoise_amd/csrc exp EXPFLAGS="-DX3_NOMFMA -DV3_NOMFMA"
+#     EXP_OUT=../lib/libxsd_hip_nomfma.so; results are garbage): what staging, LDS, stores and HBM traffic cost by themselves
+if [ -f xmm-superres-denoise_amd/lib/libxsd_hip_nomfma.so ]; then
+  XSD_LIB=$PWD/xmm-superres-denoise_amd/lib/libxsd_hip_nomfma.so python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']
+print('dn_train without MFMAs', round(d['value'], 1), 'tiles/s', round(d['ms_per_step'], 1), 'ms/step  conv', round(r['avg_launch_ms'], 3), 'ms  wgrad', round(r['wgrad_kernel']['avg_launch_ms'], 3), 'ms', d.get('power'))" >> $O
+  tail -1 $O
+fi

@@ -411,6 +411,10 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
             for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const f16x8*>(xc + t * X3_XT + abase[dx] + ir * X3_ROWB);
         };
         auto mac = [&](int r, const f16x8 (&w)[2], const f16x8 (&x)[2]) {
+#ifdef X3_NOMFMA   // energy experiment (tools/power_table.sh): the whole kernel but its matrix instructions -- results are garbage
+            asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(x[0]), "v"(x[1]));
+            return;
+#endif
             accx[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], x[1], accx[r], 0, 0, 0);   // Wh * Xl   } weighted 2^-11
             accx[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1], x[0], accx[r], 0, 0, 0);   // Wl * Xh   } in the epilogue
             acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], x[0], acc[r], 0, 0, 0);     // Wh * Xh

@@ -185,6 +185,8 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
     constexpr int abl = XSD_ABL;     // staging waves: 1 no split, 2 no LDS writes, 4 no loads and no counted waits, 128 nothing but the barrier;
                                      // MFMA waves: 32 no MFMAs (fragment reads only), 256 no fragment reads (MFMAs only), 64 nothing but the barrier
                                      // (results are garbage: read the stamps' CYCLES, not milliseconds -- degenerate operands raise the clock)
+#elif defined(V3_NOMFMA)   // energy experiment (tools/power_table.sh): the whole kernel but its matrix instructions
+    constexpr int abl = 32;
 #else
     constexpr int abl = 0;
 #endif
