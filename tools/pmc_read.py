@@ -7,7 +7,7 @@ for i in (1, 2):
     f = glob.glob(os.path.join(ROOT, 'gpurun_out', f'pmc_{tag}_{i}', '*', '*counter_collection.csv'))[0]
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if 'conv3x3' not in k and not ('wgrad_' in k and 'reduce' not in k): continue
+        if 'conv3x3' not in k and not (('wgrad_h2x' in k or 'wgrad_s3x' in k or 'wgrad_mfma' in k) and 'reduce' not in k): continue   # (not the edge layers' edge_wgrad_*)
         name = 'conv' if 'conv3x3' in k else 'wgrad'
         agg[name][r['Counter_Name']] += float(r['Counter_Value'])
         if r['Counter_Name'] in ('SQ_WAVE_CYCLES', 'SQ_WAIT_INST_LDS'): cnt[(name, i)] += 1

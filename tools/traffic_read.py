@@ -11,7 +11,7 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"{ROOT}/gpurun_out/traffic_{math}_{C}/*/*counter_collection.csv")[0]
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        name = "conv" if "conv3x3" in k else ("wgrad" if ("wgrad_" in k and "reduce" not in k) else None)
+        name = "conv" if "conv3x3" in k else ("wgrad" if (("wgrad_h2x" in k or "wgrad_s3x" in k or "wgrad_mfma" in k) and "reduce" not in k) else None)   # (not the edge layers' edge_wgrad_*)
         if name is None or r["Counter_Name"] != C:
             continue
         agg[name][C] += float(r["Counter_Value"])

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReducePar
     const int total = R.n_g * R.n_in * 9 * 1024;        // multiple of 256
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int e4 = blockIdx.x * 256 + lane * 4;
-    const long long stride = (long long)R.n_g * R.n_in * 9 * 1024;
+    const long long stride = R.part_stride ? R.part_stride : (long long)R.n_g * R.n_in * 9 * 1024;
     const int per = (R.nparts + 15) / 16;
     const int p0 = w * per, p1 = min(R.nparts, p0 + per);
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -207,6 +207,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReducePar
     // bias: block 0; the same 16 x (P/16) fixed-order scheme (a serial 256-load chain here used to cost 60 us per launch)
     if (blockIdx.x == 0) {
         const int nb = R.n_g * 32; // <= 128 entries (n, co)
+        const long long bstride = R.bias_stride ? R.bias_stride : nb;
         __syncthreads();
         for (int base = 0; base < nb; base += 64) {
             const int idx = base + lane;
@@ -216,11 +217,11 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReducePar
                 for (; p + 8 <= p1; p += 8) {
                     float v[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = R.bias_partial[(long long)(p + u) * nb + idx];
+                    for (int u = 0; u < 8; ++u) v[u] = R.bias_partial[(long long)(p + u) * bstride + idx];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) t += (double)v[u];
                 }
-                for (; p < p1; ++p) t += (double)R.bias_partial[(long long)p * nb + idx];
+                for (; p < p1; ++p) t += (double)R.bias_partial[(long long)p * bstride + idx];
             }
             if (idx < 256) red[w][idx] = t;
         }

@@ -398,6 +398,61 @@ struct Builder {
         });
     }
 
+    // A dense block's FIFTEEN (X_j, G_n) pairs (conv n + 1 reads x_0 .. x_n: j <= n) as ONE pair-list launch of the f16x3 kernel:
+    // 16 parts x 15 slots = 240 workgroups, the 15 of a part side by side on one XCD walking the same tiles, so that every X and
+    // every G tile comes from HBM once and from that XCD's L2 for the other pairs (10 planes read instead of the 20 of five
+    // launches per G).  The step runs at the package power cap and HBM traffic is a third of a launch's dynamic energy
+    // (DESIGN.md 6.5): bytes are what there is to save; the 16 CUs the launch leaves idle draw next to nothing.
+    // Slots are conv-major (conv 5 first), so conv n's blocks are contiguous and each conv gets its own fixed-order reduce.
+    void wgrad_block_launch(std::vector<Launch>& ops, const float* const xpl[5], const float* const Gp[6], const ConvW* cw, float gscale)
+    {
+        xsd_engine* eng = e;
+        WgradParams wp;
+        memset(&wp, 0, sizeof(wp));
+        wp.B = B; wp.H = H; wp.W = W;
+        wp.tilesX = (wp.W + TILE_W - 1) / TILE_W; wp.tilesY = (wp.H + TILE_H - 1) / TILE_H;
+        wp.n_in = 5; wp.n_g = 5; wp.nparts = 16; wp.npairs = 15;
+        std::vector<Launch> pre;
+        for (int i = 0; i < 5; ++i) {
+            wp.x[i] = std_in(xpl[i], 0); wp.g[i] = std_in(Gp[i + 1], 0);      // g[n] = G_{n+1}, the gradient at conv n+1's output
+            wp.amax_x[i] = slot_of(wp.x[i], wp.H, wp.W, pre);
+            wp.amax_g[i] = slot_of(wp.g[i], wp.H, wp.W, pre);
+        }
+        int first[5], slot = 0;
+        for (int n = 4; n >= 0; --n) {
+            first[n] = slot;
+            for (int j = 0; j <= n; ++j, ++slot) { wp.pair_j |= (unsigned long long)j << (4 * slot); wp.pair_n |= (unsigned long long)n << (4 * slot); }
+        }
+        WgradReduceParams rp[5];
+        long long w_off[5], b_off[5];
+        for (int n = 0; n < 5; ++n) {
+            memset(&rp[n], 0, sizeof(rp[n]));
+            rp[n].nparts = wp.nparts; rp[n].n_in = n + 1; rp[n].n_g = 1; rp[n].cin_total = cw[n].cin; rp[n].cout_total = cw[n].cout;
+            rp[n].shuffle = 0; rp[n].scale = n == 4 ? gscale : 1.f;
+            rp[n].part_stride = (long long)wp.npairs * PANEL_FLOATS; rp[n].bias_stride = wp.n_g * 32;
+            w_off[n] = cw[n].w_off; b_off[n] = cw[n].b_off;
+        }
+        const double px = (double)wp.B * wp.H * wp.W;
+        const double flop = 2.0 * 9 * 32 * 32 * 15 * px;
+        const double bytes = 128.0 * 10 * px;      // SURVEY 8(d) rule: every X plane and every G plane once
+        std::vector<long long> wo(w_off, w_off + 5), bo(b_off, b_off + 5);
+        std::vector<WgradReduceParams> rps(rp, rp + 5);
+        std::vector<int> fst(first, first + 5);
+        ops.push_back([eng, wp, rps, fst, pre, wo, bo, flop, bytes](hipStream_t s) mutable {
+            for (auto& f : pre) { hipError_t perr = f(s); if (perr != hipSuccess) return perr; }
+            wp.partial = eng->wg_partial; wp.bias_partial = eng->wg_bias_partial;
+            wp.zero = eng->zero_page; wp.ablate = eng->ablate; wp.dbg = eng->dbg;
+            hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return launch_wgrad_split(eng->math, eng->ablate, wp, s); });
+            for (int n = 0; n < 5 && err == hipSuccess; ++n) {
+                WgradReduceParams r = rps[n];
+                r.partial = eng->wg_partial + (long long)fst[n] * PANEL_FLOATS; r.bias_partial = eng->wg_bias_partial + n * 32;
+                r.dw = eng->b_grads + wo[n]; r.db = eng->b_grads + bo[n];
+                err = launch_wgrad_reduce(r, s);
+            }
+            return err;
+        });
+    }
+
     // ---------------------------------------------------------------------------------------------------------
     void build()
     {
@@ -588,10 +643,15 @@ struct Builder {
                 // lrelu'(x_j) (j >= 1), which makes dS_j the G_j of conv_j.  conv5's 0.2 / 0.04 factor lives in its
                 // transposed panels (PackDesc.bwd_scale); its weight gradient uses the unscaled dOut and scales in the reduce.
                 const float* Gp[6] = {nullptr, dS[1], dS[2], dS[3], dS[4], dOut}; // G_c, c = 1..5
+                // one pair-list weight-gradient launch per dense block (f16x3 kernel) once every G exists, i.e. in front of dS_0
+                // (XSD_WGRAD_BLOCK=0 restores one launch per G for same-library A/Bs: 122.6 -> 125.6 tiles/s on one device, profiles/r04_ab_wgrad_block_launch.txt)
+                static const bool block_wgrad = getenv("XSD_WGRAD_BLOCK") ? atoi(getenv("XSD_WGRAD_BLOCK")) != 0 : true;
+                const bool mega = block_wgrad && e->math == 4 && !(e->ablate & (1 << 22));
                 for (int c = 4; c >= 0; --c) { // conv index c (0-based) = conv_{c+1}
                     std::vector<PlaneIn> xs;
                     for (int kk = 0; kk <= c; ++kk) xs.push_back(std_in(xpl[kk], 0));
-                    wgrad_launch(S, 0, xs, {std_in(Gp[c + 1], 0)}, cw[c], c == 4 ? gscale : 1.f);
+                    if (!mega) wgrad_launch(S, 0, xs, {std_in(Gp[c + 1], 0)}, cw[c], c == 4 ? gscale : 1.f);
+                    else if (c == 0) wgrad_block_launch(S, xpl, Gp, cw, gscale);
                     // now every G needed by dS_c exists: G_5 .. G_{c+1}
                     const int j = c;
                     ConvParams p = conv_base(0);

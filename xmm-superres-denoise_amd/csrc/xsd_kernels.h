@@ -115,15 +115,21 @@ struct WgradParams {
     int n_g;             // number of 32-channel G chunks (1, or 4 for the pixel-shuffle conv)
     int tilesX, tilesY, nparts;
     PlaneIn x[5];
-    PlaneIn g[4];
-    float* partial;      // [nparts][n_g][n_in][9][32 ci][32 co]
+    PlaneIn g[5];
+    float* partial;      // [nparts][n_g][n_in][9][32 ci][32 co]; pair-list launches: [nparts][npairs][9][32 ci][32 co]
     float* bias_partial; // [nparts][n_g][32]
     const void* zero;    // zero page
     int ablate;          // diagnostic (env XSD_ABLATE): 4096 = request the G tile only for the first tile of a workgroup
     int pad_;
     unsigned long long* dbg; // diagnostic phase stamps (null in production): slots [8..15] of the engine's stamp buffer
     const float* amax_x[5]; // math mode 4 (f16x3): max |x| slots of the X and G planes
-    const float* amax_g[4];
+    const float* amax_g[5];
+    // Pair-list launch (wgrad_h2x only; npairs = 0: the full n_in x n_g rectangle): workgroup slot s of a part multiplies X plane
+    // (pair_j >> 4s) & 15 with G plane (pair_n >> 4s) & 15.  All slots of a part run side by side on one XCD and walk the same
+    // tiles, so every X and every G tile of the launch comes from HBM once and from that XCD's L2 for the other pairs that use it
+    // (a dense block's 15 (X_j, G_n) pairs: 10 planes read instead of 20).  Grid = nparts * npairs workgroups, nparts a multiple of 8.
+    int npairs, pad2_;
+    unsigned long long pair_j, pair_n;
 };
 
 struct WgradReduceParams {
@@ -137,6 +143,9 @@ struct WgradReduceParams {
     float scale;
     float* dw;     // OIHW [cout_total][cin_total][3][3]
     float* db;     // [cout_total]
+    long long part_stride;   // floats between two parts' partial sums (0: n_g * n_in * 9 * 1024, the launch's own rectangle)
+    int bias_stride;         // entries between two parts' bias sums (0: n_g * 32)
+    int pad_;
 };
 
 // pack descriptor: one conv's OIHW weights -> forward and transposed (dgrad) panels
