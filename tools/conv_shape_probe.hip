@@ -40,7 +40,7 @@ __global__ __launch_bounds__(512) void probe_kernel(const unsigned int* __restri
     const char* wl = smem + WOFF;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     float sink = 0.f;
-    if constexpr (SHAPE == 0) {
+    if constexpr (SHAPE == 0 || SHAPE == 3) {
         f32x16 acc[2], accx[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -66,17 +66,26 @@ __global__ __launch_bounds__(512) void probe_kernel(const unsigned int* __restri
             accx[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1], x[0], accx[r], 0, 0, 0);
             acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], x[0], acc[r], 0, 0, 0);
         };
+        f16x8 xf[3][2], wf[3][2];
+        if (SHAPE == 3) {      // fragments resident: the MFMA sequence of shape A without its 42 LDS reads per half-step (what do they cost?)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { load_x(q, q, xf[q]); load_w(q, wf[q]); }
+        }
 #pragma unroll 1
         for (int it = 0; it < iters; ++it) {
-            f16x8 xf[3][2], wf[3][2];
+            if (SHAPE == 0) {
             load_x(0, 0, xf[0]);
             load_w(0, wf[0]);
             load_x(1, 0, xf[1]);
             load_w(3, wf[1]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { asm volatile("" : "+v"(xf[q][0]), "+v"(xf[q][1]), "+v"(wf[q][0]), "+v"(wf[q][1])); }
+            }
 #pragma unroll
             for (int s = 0; s < 12; ++s) {
                 const int dx = s >> 2, ir = s & 3;
-                if (s + 2 < 12) {
+                if (SHAPE == 0 && s + 2 < 12) {
                     const int dx2 = (s + 2) >> 2, ir2 = (s + 2) & 3;
                     load_x(ir2, dx2, xf[(s + 2) % 3]);
                     if (ir2 <= 2) load_w(ir2 * 3 + dx2, wf[(3 * dx2 + ir2) % 3]);
@@ -209,18 +218,20 @@ int main(int argc, char** argv)
     hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<unsigned long long> clk(2 * G);
     printf("conv_shape_probe: %d CUs, %d half-steps per launch; per wave and half-step: A = 54 x 32x32x16 + 42 ds_read_b128, B = 120 x 16x16x32 + 60 ds_read_b128\n", G, iters);
     for (int rep = 0; rep < 3; ++rep)
-        for (int shape = 0; shape < 3; ++shape) {
+        for (int shape = 0; shape < 4; ++shape) {
             if (only >= 0 && shape != only) continue;
             for (int pass = 0; pass < 2; ++pass) {          // pass 0 warms the clock governor up, pass 1 is reported
                 hipEventRecord(e0, 0);
                 if (shape == 0) hipLaunchKernelGGL(probe_kernel<0>, dim3(G), dim3(512), LDS_BYTES, 0, d_src, d_out, d_clk, iters);
                 else if (shape == 1) hipLaunchKernelGGL(probe_kernel<1>, dim3(G), dim3(512), LDS_BYTES, 0, d_src, d_out, d_clk, iters);
-                else hipLaunchKernelGGL(probe_kernel<2>, dim3(G), dim3(512), LDS_BYTES, 0, d_src, d_out, d_clk, iters);
+                else if (shape == 2) hipLaunchKernelGGL(probe_kernel<2>, dim3(G), dim3(512), LDS_BYTES, 0, d_src, d_out, d_clk, iters);
+                else hipLaunchKernelGGL(probe_kernel<3>, dim3(G), dim3(512), LDS_BYTES, 0, d_src, d_out, d_clk, iters);
                 hipEventRecord(e1, 0);
                 hipEventSynchronize(e1);
             }
@@ -230,9 +241,9 @@ int main(int argc, char** argv)
             std::vector<double> cyc(G), ghz(G);
             for (int g = 0; g < G; ++g) { cyc[g] = (double)clk[2 * g] / iters; ghz[g] = (double)clk[2 * g] / ((double)clk[2 * g + 1] * 10.0); }   // s_memrealtime: 100 MHz
             std::sort(cyc.begin(), cyc.end()); std::sort(ghz.begin(), ghz.end());
-            const double pipe = shape == 0 ? 2 * 54 * 32.0 : (shape == 1 ? 2 * 120 * 16.0 : 2 * 108 * 16.0);      // matrix-pipe cycles per half-step and SIMD (two waves)
+            const double pipe = (shape == 0 || shape == 3) ? 2 * 54 * 32.0 : (shape == 1 ? 2 * 120 * 16.0 : 2 * 108 * 16.0);      // matrix-pipe cycles per half-step and SIMD (two waves)
             printf("  shape %c: %8.1f cycles per half-step (matrix pipe needs %.0f: %.0f %% busy), in-kernel clock %.3f GHz, %7.3f us per half-step wall\n",
-                   "ABC"[shape], cyc[G / 2], pipe, 100.0 * pipe / cyc[G / 2], ghz[G / 2], 1e3 * ms / iters);
+                   "ABCD"[shape], cyc[G / 2], pipe, 100.0 * pipe / cyc[G / 2], ghz[G / 2], 1e3 * ms / iters);
         }
     return 0;
 }
