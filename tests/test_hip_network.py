@@ -472,8 +472,9 @@ def test_wide_plane_nets_in_every_math_mode(kind, nf, blocks, nup, shape, math):
     _widths_vs_float64(kind, nf, 1, 1, blocks, nup, shape, math=math)
 
 
-def test_block_weight_gradient_launch_equals_one_launch_per_g(tmp_path):
-    """The f16x3 weight gradient of a dense block runs as ONE pair-list launch over its 15 (X, G) pairs (DESIGN.md 6.5);
+@pytest.mark.parametrize("math", ["f16x3", "bf16x6"])
+def test_block_weight_gradient_launch_equals_one_launch_per_g(tmp_path, math):
+    """The split-precision weight gradients of a dense block run as ONE pair-list launch over its 15 (X, G) pairs (DESIGN.md 6.5);
     XSD_WGRAD_BLOCK=0 restores one launch per G.  Same products, same per-workgroup tile order inside a pair, a different cut
     of the tiles into partial sums (16 chunks instead of 256 / pairs): the two gradients agree to fp32 summation-order level.
     The switch is read once per process, so each variant runs in a child."""
@@ -486,7 +487,7 @@ def test_block_weight_gradient_launch_equals_one_launch_per_g(tmp_path):
         "for p in (root, os.path.join(root, 'xmm-superres-denoise_amd'), os.path.join(root, 'tests'), os.path.join(root, 'tests', 'golden')): sys.path.insert(0, p)\n"
         "from xmm_superres_denoise.models import GeneratorRRDB_DN\n"
         "torch.manual_seed(5)\n"
-        "m = GeneratorRRDB_DN(1, 1, 32, 2).cuda().set_math('f16x3')\n"
+        "m = GeneratorRRDB_DN(1, 1, 32, 2).cuda().set_math(sys.argv[3])\n"
         "x = torch.rand(3, 1, 72, 100, device='cuda', requires_grad=True); t = torch.rand(3, 1, 72, 100, device='cuda')\n"
         "y = m(x); loss = (y - t).abs().mean(); loss.backward()\n"
         "g = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()}\n"
@@ -496,7 +497,7 @@ def test_block_weight_gradient_launch_equals_one_launch_per_g(tmp_path):
     for sw in ("1", "0"):
         out = str(tmp_path / f"g{sw}.npz")
         env = dict(os.environ, XSD_WGRAD_BLOCK=sw)
-        p = subprocess.run([sys.executable, "-c", code, root, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        p = subprocess.run([sys.executable, "-c", code, root, out, math], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
         outs.append(np.load(out))
     a, b = outs

@@ -1,0 +1,9 @@
+# same-library, same-device A/B of an engine switch read from the environment, in a chosen math mode: bash tools/ab_env_math.sh VAR MATH
+V=$1; M=$2
+for R in 0 1 0 1; do
+  export $V=$R
+  timeout -k 10 300 python bench.py --math $M --steps 8 --warmup 3 --no-extra --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']; w = r['wgrad_kernel']
+print('$M $V=$R', round(d['value'], 2), 'tiles/s', round(d['ms_per_step'], 1), 'ms  conv', round(r['avg_launch_ms'], 4), ' wgrad', round(w['avg_launch_ms'], 4), 'x', w['launches'], '= %.1f ms/step' % (w['avg_launch_ms'] * w['launches'] / d['steps']))"
+done

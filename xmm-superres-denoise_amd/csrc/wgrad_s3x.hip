@@ -75,11 +75,19 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
     // 1-D grid decode: the n_in workgroups that read the SAME G tiles have linear ids 8 apart -> one XCD
     const int lin = blockIdx.x;
     const int xcd = lin & 7, qq = lin >> 3;
-    const int j = qq % P.n_in;                        // input plane
-    const int rest = qq / P.n_in;
     const int parts8 = P.nparts >> 3;
-    const int part = (rest % parts8) * 8 + xcd;
-    const int n = rest / parts8;                      // G chunk
+    int j, n, part, slot = 0;
+    if (P.npairs > 0) {                               // pair-list launch (xsd_kernels.h): slot = pair, all slots of a part side by side on one XCD
+        slot = qq % P.npairs;
+        part = (qq / P.npairs) * 8 + xcd;
+        j = (int)((P.pair_j >> (4 * slot)) & 15);
+        n = (int)((P.pair_n >> (4 * slot)) & 15);
+    } else {
+        j = qq % P.n_in;                              // input plane
+        const int rest = qq / P.n_in;
+        part = (rest % parts8) * 8 + xcd;
+        n = rest / parts8;                            // G chunk
+    }
     const int tilesY = (P.H + V3_TH - 1) / V3_TH;
     const int ntiles = P.B * tilesY * P.tilesX;
     const int my_tiles = part < ntiles ? (ntiles - part + P.nparts - 1) / P.nparts : 0;
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
     // ---- cross-wave reduction through LDS, one tap at a time (one 4 KiB slab per MFMA wave), then one coalesced store per tap
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
-    float* outp = P.partial + ((((long long)part * P.n_g + n) * P.n_in + j) * 9) * 1024;
+    float* outp = P.partial + (P.npairs > 0 ? ((long long)part * P.npairs + slot) * 9 : (((long long)part * P.n_g + n) * P.n_in + j) * 9) * 1024;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         if (!loader) {
@@ -360,7 +368,10 @@ hipError_t launch_wgrad_s3x(const WgradParams& p, hipStream_t stream)
     // 32-bit byte offsets inside one batch slice of a plane (buffer loads); xsd_forward rejects such images with a message
     for (int i = 0; i < p.n_in; ++i) if ((long long)p.H * p.x[i].rs * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     for (int i = 0; i < p.n_g; ++i) if ((long long)p.H * p.g[i].rs * 4 >= (1ll << 31)) return hipErrorInvalidValue;
-    const dim3 g(p.nparts * p.n_in * p.n_g), b(V3_THREADS);
+    if (p.npairs < 0 || p.npairs > 16 || p.n_in > 5 || p.n_g > 5) return hipErrorInvalidValue;
+    for (int s = 0; s < p.npairs; ++s)
+        if ((int)((p.pair_j >> (4 * s)) & 15) >= p.n_in || (int)((p.pair_n >> (4 * s)) & 15) >= p.n_g) return hipErrorInvalidValue;
+    const dim3 g(p.nparts * (p.npairs > 0 ? p.npairs : p.n_in * p.n_g)), b(V3_THREADS);
     hipLaunchKernelGGL(wgrad_s3x_kernel, g, b, V3_LDS_BYTES, stream, p);
     return hipGetLastError();
 }

@@ -415,8 +415,10 @@ struct Builder {
         std::vector<Launch> pre;
         for (int i = 0; i < 5; ++i) {
             wp.x[i] = std_in(xpl[i], 0); wp.g[i] = std_in(Gp[i + 1], 0);      // g[n] = G_{n+1}, the gradient at conv n+1's output
-            wp.amax_x[i] = slot_of(wp.x[i], wp.H, wp.W, pre);
-            wp.amax_g[i] = slot_of(wp.g[i], wp.H, wp.W, pre);
+            if (e->math == 4) {
+                wp.amax_x[i] = slot_of(wp.x[i], wp.H, wp.W, pre);
+                wp.amax_g[i] = slot_of(wp.g[i], wp.H, wp.W, pre);
+            }
         }
         int first[5], slot = 0;
         for (int n = 4; n >= 0; --n) {
@@ -646,7 +648,7 @@ struct Builder {
                 // one pair-list weight-gradient launch per dense block (f16x3 kernel) once every G exists, i.e. in front of dS_0
                 // (XSD_WGRAD_BLOCK=0 restores one launch per G for same-library A/Bs: 122.6 -> 125.6 tiles/s on one device, profiles/r04_ab_wgrad_block_launch.txt)
                 static const bool block_wgrad = getenv("XSD_WGRAD_BLOCK") ? atoi(getenv("XSD_WGRAD_BLOCK")) != 0 : true;
-                const bool mega = block_wgrad && e->math == 4 && !(e->ablate & (1 << 22));
+                const bool mega = block_wgrad && e->math >= 3;      // both role-split weight-gradient kernels take pair lists
                 for (int c = 4; c >= 0; --c) { // conv index c (0-based) = conv_{c+1}
                     std::vector<PlaneIn> xs;
                     for (int kk = 0; kk <= c; ++kk) xs.push_back(std_in(xpl[kk], 0));
