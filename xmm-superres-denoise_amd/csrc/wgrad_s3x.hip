@@ -80,6 +80,10 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
     if (P.npairs > 0) {                               // pair-list launch (xsd_kernels.h): slot = pair, all slots of a part side by side on one XCD
         slot = qq % P.npairs;
         part = (qq / P.npairs) * 8 + xcd;
+        // nparts = 8 m + 1: the last part has no XCD of its own -- its slots are dealt over the CUs the m parts per XCD leave
+        // (slot = 8 e + xcd for the e-th spare workgroup of an XCD); it shares nothing through L2, but no CU idles
+        const int full = parts8 * P.npairs;
+        if (qq >= full) { slot = (qq - full) * 8 + xcd; part = P.nparts - 1; if (slot >= P.npairs) return; }
         j = (int)((P.pair_j >> (4 * slot)) & 15);
         n = (int)((P.pair_n >> (4 * slot)) & 15);
     } else {
@@ -364,14 +368,16 @@ hipError_t launch_wgrad_s3x(const WgradParams& p, hipStream_t stream)
                                    hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS_BYTES);
     }, nullptr);
     if (e != hipSuccess) return e;
-    if (p.nparts & 7) return hipErrorInvalidValue;
+    if ((p.nparts & 7) && !(p.npairs > 0 && (p.nparts & 7) == 1)) return hipErrorInvalidValue;
     // 32-bit byte offsets inside one batch slice of a plane (buffer loads); xsd_forward rejects such images with a message
     for (int i = 0; i < p.n_in; ++i) if ((long long)p.H * p.x[i].rs * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     for (int i = 0; i < p.n_g; ++i) if ((long long)p.H * p.g[i].rs * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     if (p.npairs < 0 || p.npairs > 16 || p.n_in > 5 || p.n_g > 5) return hipErrorInvalidValue;
     for (int s = 0; s < p.npairs; ++s)
         if ((int)((p.pair_j >> (4 * s)) & 15) >= p.n_in || (int)((p.pair_n >> (4 * s)) & 15) >= p.n_g) return hipErrorInvalidValue;
-    const dim3 g(p.nparts * (p.npairs > 0 ? p.npairs : p.n_in * p.n_g)), b(V3_THREADS);
+    // pair lists with nparts = 8 m + 1: m * npairs workgroups per XCD for the full parts + ceil(npairs / 8) per XCD for the last part
+    const int pair_grid = 8 * ((p.nparts >> 3) * p.npairs + ((p.nparts & 7) ? (p.npairs + 7) / 8 : 0));
+    const dim3 g(p.npairs > 0 ? pair_grid : p.nparts * p.n_in * p.n_g), b(V3_THREADS);
     hipLaunchKernelGGL(wgrad_s3x_kernel, g, b, V3_LDS_BYTES, stream, p);
     return hipGetLastError();
 }

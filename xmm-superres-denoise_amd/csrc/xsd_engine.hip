@@ -399,7 +399,7 @@ struct Builder {
     }
 
     // A dense block's FIFTEEN (X_j, G_n) pairs (conv n + 1 reads x_0 .. x_n: j <= n) as ONE pair-list launch of the f16x3 kernel:
-    // 16 parts x 15 slots = 240 workgroups, the 15 of a part side by side on one XCD walking the same tiles, so that every X and
+    // 16 parts x 15 slots = 240 workgroups (+ a 17th part on the 16 spare CUs), the 15 of a part side by side on one XCD walking the same tiles, so that every X and
     // every G tile comes from HBM once and from that XCD's L2 for the other pairs (10 planes read instead of the 20 of five
     // launches per G).  The step runs at the package power cap and HBM traffic is a third of a launch's dynamic energy
     // (DESIGN.md 6.5): bytes are what there is to save; the 16 CUs the launch leaves idle draw next to nothing.
@@ -412,6 +412,9 @@ struct Builder {
         wp.B = B; wp.H = H; wp.W = W;
         wp.tilesX = (wp.W + TILE_W - 1) / TILE_W; wp.tilesY = (wp.H + TILE_H - 1) / TILE_H;
         wp.n_in = 5; wp.n_g = 5; wp.nparts = 16; wp.npairs = 15;
+        // a 17th part on the 16 CUs the 16 x 15 workgroups leave: two of its slots per XCD, no L2 sharing for it, no idle CU
+        // (XSD_WGRAD_TAIL=0: 16 parts; same device 124.7 -> 125.2 tiles/s, the kernel -1.9 %)
+        { static const int tail = getenv("XSD_WGRAD_TAIL") ? atoi(getenv("XSD_WGRAD_TAIL")) : 1; if (tail) wp.nparts = 17; }
         std::vector<Launch> pre;
         for (int i = 0; i < 5; ++i) {
             wp.x[i] = std_in(xpl[i], 0); wp.g[i] = std_in(Gp[i + 1], 0);      // g[n] = G_{n+1}, the gradient at conv n+1's output
