@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams
     for (int tap = 0; tap < 9; ++tap) w4[tap] = *reinterpret_cast<const f32x4*>(P.w + tap * 32 + q * 4);
     const f32x4 b4 = P.bias ? *reinterpret_cast<const f32x4*>(P.bias + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     const int nrows = P.B * P.H;
+    float vmax = 0.f;      // max |value written| by this thread (reported only when P.amax is set)
     for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int y = row % P.H;
         const float* sb = P.s + (P.s_bs ? (long long)(row / P.H) * P.s_bs : (long long)(row - y) * P.W);
@@ -51,7 +52,14 @@ __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams
                 for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : v[i] * P.mslope;
             }
             *reinterpret_cast<f32x4*>(P.out + o + q * 4) = v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vmax = fmaxf(vmax, fabsf(v[i]));
         }
+    }
+    if (P.amax) {          // wave maximum by shuffles, one atomic per wave (non-negative floats order as unsigned integers; NaN never wins fmaxf)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(P.amax), __float_as_uint(vmax));
     }
 }
 

@@ -216,6 +216,16 @@ struct Builder {
             if (k >= lo && k < lo + bytes) it = amax_valid.erase(it); else ++it;
         }
     }
+    // a producer outside the conv kernels (edge_expand) reports the max |x| of the standard plane it writes
+    float* report_slot(float* plane, int level)
+    {
+        if (e->math != 4) return nullptr;
+        const PlaneIn v = std_in(plane, level);
+        invalidate_range(reinterpret_cast<uintptr_t>(plane), plane_bytes(level));
+        float* slot = new_slot();
+        amax_valid[ViewKey(reinterpret_cast<uintptr_t>(v.p), v.rs, v.ps)] = slot;
+        return slot;
+    }
     // slot of an input view; if nobody has reported it yet, `pre` gets the reduction launch
     float* slot_of(const PlaneIn& v, int Hv, int Wv, std::vector<Launch>& pre)
     {
@@ -480,6 +490,7 @@ struct Builder {
         { // conv_first (generator_rrdb.py:67)
             EdgeExpandParams p; memset(&p, 0, sizeof(p));
             p.B = B; p.H = H; p.W = W; p.out = fea; p.w = e->pk_edge + 0; p.mslope = 1.f;
+            p.amax = report_slot(fea, 0);
             const long long boff = e->first_b;
             F.push_back([eng, p, boff](hipStream_t s) mutable { p.s = eng->b_x; p.bias = eng->params + boff; return launch_edge_expand(p, s); });
         }
@@ -589,12 +600,14 @@ struct Builder {
             if (!sr) {
                 EdgeExpandParams p; memset(&p, 0, sizeof(p));
                 p.B = B; p.H = H; p.W = W; p.s = dpre; p.w = e->pk_edge + 3 * 288; p.out = dT; p.mslope = 1.f;
+                p.amax = report_slot(dT, 0);
                 S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
             } else {
                 float* GH = alloc(lo);
                 { // d(H1) masked by lrelu'(0.2)
                     EdgeExpandParams p; memset(&p, 0, sizeof(p));
                     p.B = B; p.H = H << lo; p.W = W << lo; p.s = dpre; p.w = e->pk_edge + 3 * 288; p.out = GH; p.mask = H1; p.mslope = 0.2f;
+                    p.amax = report_slot(GH, lo);
                     S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
                 }
                 const float* hr_in = nup > 0 ? U[nup - 1] : T;

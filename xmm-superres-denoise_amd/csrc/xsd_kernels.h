@@ -170,6 +170,8 @@ struct EdgeExpandParams { // 1 -> 32 conv:  out[p][c] = bias[c] + sum_tap s[p+ta
     const unsigned short* bits; // compact form of `mask` (OutDesc::bits_out layout) or null
     long long s_bs;      // floats between consecutive images of `s` (0: H*W; C*H*W when `s` is one channel of a [B][C][H][W] image)
     int accumulate;      // add to what `out` holds instead of starting from the bias (second and later image channels)
+    float* amax;         // math mode 4: slot that receives max |out| (atomic max over non-negative floats as integers), or null --
+                         // the consumers scale their operands by it; without it the engine sweeps the plane once more (plane_amax_kernel)
 };
 struct EdgeReduceParams { // 32 -> 1 conv: pre[p] = bias + sum_tap sum_c f[p+tap][c] * w[tap][c] (+ skip[p]); y = clamp(pre)
     int B, H, W;
