@@ -111,7 +111,7 @@ class PowerWatch:
     freq1_input, power1_cap) while the timed region runs -- a reader thread, no subprocess, nothing on the GPU.  `pci` names the
     devices by PCI address prefix ("0000:05:00", from torch's device properties): a GPU box shows the hwmon files of every card
     of its host, other tenants' included.  Without it (tools, tests) the busiest device is reported and the source says so.
-    The train step of this engine runs AT the package power cap (DESIGN.md 6.5): the clock the chip holds, and with it every
+    The train step of this engine runs AT the package power cap (DESIGN.md section 6): the clock the chip holds, and with it every
     kernel's milliseconds, is set by the energy a tile costs, so the line reports what was drawn beside what was computed.
     Returns None where the files are not readable (no GPU, other driver)."""
 
@@ -154,30 +154,37 @@ class PowerWatch:
                     d["mhz"].append(f * 1e-6)
             self._stop.wait(self.period)
 
-    def __enter__(self):
-        if self._thr:
+    def start(self):
+        """called right after the synchronize() that closes the warm-up: every sample lies inside the timed region"""
+        if self._thr and not self._thr.is_alive():
             self._thr.start()
+
+    def stop(self):
+        if self._thr and self._thr.is_alive():
+            self._stop.set()
+            self._thr.join()
+
+    def __enter__(self):
+        self.start()
         return self
 
     def __exit__(self, *a):
-        if self._thr:
-            self._stop.set()
-            self._thr.join()
+        self.stop()
 
     def summary(self):
         best = None
         avgs = []
         for d in self.devs:
-            w = d["w"][len(d["w"]) // 5:]            # the first fifth is the ramp from idle
+            w = d["w"]              # every sample: the reader runs from the post-warm-up synchronize() to the closing one
             if len(w) < 3:
                 continue
             avgs.append(round(sum(w) / len(w), 1))
             if best is None or sum(w) / len(w) > best["avg_w"]:
-                mhz = d["mhz"][len(d["mhz"]) // 5:]
+                mhz = d["mhz"]
                 cap = self._read(d["cap"])
                 best = {"avg_w": round(sum(w) / len(w), 1), "max_w": round(max(w), 1), "cap_w": round(cap * 1e-6, 1) if cap else None,
                         "sclk_mhz": round(sum(mhz) / len(mhz), 0) if mhz else None, "samples": len(w), "pci": d["pci"],
-                        "source": "sysfs hwmon of %s, sampled every %.0f ms over the timed region (first fifth dropped)" %
+                        "source": "sysfs hwmon of %s, sampled every %.0f ms between the synchronize() that closes the warm-up and the one that closes the timed steps" %
                                   ("this job's device(s), by PCI address" if self.matched else "the BUSIEST amdgpu device of the host (not matched to this job)", 1e3 * self.period)}
         if best and best["cap_w"]:
             best["frac_of_cap"] = round(best["avg_w"] / best["cap_w"], 3)
@@ -227,7 +234,7 @@ STEP_BYTES = {("dn", True): 117020.0, ("dn", False): 33420.0, ("sr", True): 1242
 STEP_FLOP = {("dn", True): 2.62e12, ("dn", False): 8.749e11, ("sr", True): 2.74e12, ("sr", False): 9.140e11}   # per tile
 
 
-def roofline_block(math, prof, batch, kind, train, world, tiles_per_s, shipped_width=True):
+def roofline_block(math, prof, batch, kind, train, world, tiles_per_s, shipped_width=True, sustained=None):
     """roofline of the dominant kernel (the conv: forward + input-gradient launches) from the HIP-event records of the timed
     region; `prof` = {0: conv totals, 1: weight-gradient totals} (Engine.profile_read)."""
     k = prof[0]
@@ -245,6 +252,14 @@ def roofline_block(math, prof, batch, kind, train, world, tiles_per_s, shipped_w
         eff_peak = BF16_MFMA_PEAK_TFLOPS / nprod
         roof = {"bound": "mfma", "kernel": MATHS[math][1], "achieved": tf, "peak": eff_peak,
                 "unit": f"TFLOP/s (algorithmic fp32 FLOP; {nprod} {'fp16' if math == 'f16x3' else 'bf16'} MFMAs each)", "frac": tf / eff_peak}
+    if sustained is not None and math in MATH_PRODUCTS:
+        sp = sustained["mfma_tflops"] / MATH_PRODUCTS[math]
+        roof.update({"sustained_peak": sp, "frac_of_sustained": tf / sp,
+                     "sustained_from": "xsd_probe_mfma_stream in this process on this device after the timed region: %.1f s of the conv's bare "
+                                       "%s MFMA-wave stream (no staging, no global traffic) reached %.0f dense TFLOP/s at %.0f MHz in-kernel clock = "
+                                       "%.3f of the nominal %.0f; / %d products per multiply"
+                                       % (sustained["seconds"], "fp16" if math == "f16x3" else "bf16", sustained["mfma_tflops"], 1e3 * sustained["sclk_ghz"],
+                                          sustained["mfma_tflops"] / BF16_MFMA_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS, MATH_PRODUCTS[math])})
     roof.update({"traffic": traffic, "traffic_from": (tfile + " (committed PMC passes of this workload; not measured in this run)") if tfile else None,
                  "hbm": hb, "launches": k["launches"], "avg_launch_ms": k["ms"] / k["launches"],
                  "algorithmic_bytes_per_launch": k["bytes"] / k["launches"], "algorithmic_flop_per_launch": k["flop"] / k["launches"]})
@@ -264,6 +279,53 @@ def roofline_block(math, prof, batch, kind, train, world, tiles_per_s, shipped_w
                           "algorithmic_TFLOPs": step_flop * per_gpu / 1e12, "fp32_mfma_frac": step_flop * per_gpu / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                           "note": "per GPU; SURVEY.md 8(d) bytes/flops per tile x tiles/s"}
     return roof
+
+
+def psnr_delta_vs_reference(kind, math, dev):
+    """PSNR(engine output, target) - PSNR(reference output, target) on the two example_data tiles of tests/golden/example_data.npz
+    (416 x 416 LR; SR: 832 x 832 HR), identical seeded weights through both: the reference's figures were written into the
+    fixture by tests/golden/make_golden.py from the imported reference modules (models/model.py:48-49 over the prepared tiles of
+    data/dataset.py:41-47); the engine runs here in `math`.  No trained weights exist offline, so this is
+    the parity of the two implementations on real count tiles, not a quality figure."""
+    import numpy as np
+    import gen_common as gc
+    from xmm_superres_denoise.data.tools import load_and_prepare
+    from xmm_superres_denoise.models import GeneratorRRDB_DN, GeneratorRRDB_SR
+    z = np.load(os.path.join(ROOT, "tests", "golden", "example_data.npz"))
+    masks = {}
+    for tag in ("1x", "2x"):
+        shp = z[f"mask{tag}_shape"]
+        masks[tag] = torch.from_numpy(np.unpackbits(z[f"mask{tag}_bits"])[: int(np.prod(shp))].reshape(shp)).to(dev)
+    if kind == "dn":
+        state = gc.make_state("dn", 32, 4, 1234)
+        m = GeneratorRRDB_DN(1, 1, 32, 4)
+    else:
+        state = gc.make_state("sr", 32, 4, 4321, last_bias=0.05)
+        m = GeneratorRRDB_SR(1, 1, 32, 4, num_upsample=1)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
+    m = m.to(dev)
+    m.set_math(math)
+    deltas, refs = [], []
+    with torch.no_grad():
+        for i in range(2):
+            if kind == "dn":
+                x = load_and_prepare(torch.from_numpy(z[f"dn_counts20_{i}"]).to(dev)[None], masks["1x"], 416, 0.0022336, "sqrt")
+                t = load_and_prepare(torch.from_numpy(z[f"dn_counts50_{i}"]).to(dev)[None], masks["1x"], 416, 0.0022336, "sqrt")
+            else:
+                x = load_and_prepare(torch.from_numpy(z[f"sr_counts_lr_{i}"]).to(dev)[None], masks["1x"], 416, 0.0022336, "sqrt")
+                t = load_and_prepare(torch.from_numpy(z[f"sr_counts_hr_{i}"]).to(dev)[None], masks["2x"], 832, 0.0005584, "sqrt")
+            y = m(x)
+            mse = float(((y.double() - t.double()) ** 2).mean())
+            ref = float(z[f"{kind}_psnr_{i}"][0])
+            refs.append(ref)
+            deltas.append(-10.0 * float(np.log10(mse)) - ref)
+    del m
+    worst = max(deltas, key=abs)
+    return {"psnr_delta_db": worst,
+            "psnr": {"delta_db_per_tile": deltas, "reference_db": refs, "math": math, "bar_db": 0.01,
+                     "tiles": "2 example_data tiles (real 20 ks counts; %s), detector mask * pad 416 * sqrt-normalize, seeded weights" %
+                              ("target 50 ks" if kind == "dn" else "target 100 ks sim at 2x, 832 x 832"),
+                     "reference_from": "tests/golden/example_data.npz (written from the imported reference by tests/golden/make_golden.py)"}}
 
 
 def self_launch(args) -> int:
@@ -305,6 +367,9 @@ def main():
     ap.add_argument("--extra-math", default="bf16x6", choices=sorted(MATHS) + ["none"],
                     help="second, labelled measurement in another math mode (same --steps/--warmup, own roofline; never the headline)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra-math leg")
+    ap.add_argument("--no-sustained", action="store_true", help="skip roofline.sustained_peak (the in-process MFMA-stream probe)")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0)
+    ap.add_argument("--no-psnr", action="store_true", help="skip psnr_delta_db (example_data tiles through the engine, outside the timed region)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -401,7 +466,8 @@ def main():
         with torch.no_grad():
             return model(x)
 
-    def timed(nwarm, nsteps, profile):
+    def timed(nwarm, nsteps, profile, watch=None):
+        """-> (max-over-ranks seconds, this rank's own seconds, profile records, exposed communication ms per step on this rank)"""
         for i in range(nwarm):
             step()
             trace(f"warm-up step {i} enqueued")
@@ -410,34 +476,54 @@ def main():
         if dp:
             dist.barrier()
         torch.cuda.synchronize()
+        if train:
+            trainer.comm_events_begin()       # event pair around the wait for the gradient exchange, read after the timed region
+        if watch is not None:
+            watch.start()
         trace("timed region starts")
         t0 = time.perf_counter()
         for _ in range(nsteps):
             step()
         torch.cuda.synchronize()
+        mine = time.perf_counter() - t0       # this rank's own K steps (before the closing barrier): the per-rank figure
         trace("timed region done")
         if dp:
             dist.barrier()
         dt = time.perf_counter() - t0
+        if watch is not None:
+            watch.stop()
         if dp:
             tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
+        comm_ms = trainer.comm_events_end() / nsteps if train else None
         prof = None
         if profile:
             prof = {0: eng.profile_read(0), 1: eng.profile_read(1)}
             eng.profile_enable(False)
-        return dt, prof
+        return dt, mine, prof, comm_ms
 
+    # every rank watches ITS OWN device (by PCI address): the per-rank block below carries each device's clock and watts
     my_pci = device_pci(dev.index if hasattr(dev, "index") and dev.index is not None else 0)
-    pcis = [my_pci]
-    if dp:      # rank 0 reads every rank's device
-        pcis = [None] * world
-        dist.all_gather_object(pcis, my_pci)
-    pcis = [p for p in pcis if p] or None
-    with PowerWatch(pci=pcis) as pwatch:
-        dt, prof = timed(args.warmup, args.steps, not args.no_profile)
-    power = pwatch.summary() if rank == 0 else None
+    pwatch = PowerWatch(pci=[my_pci] if my_pci else None)
+    dt, my_dt, prof, comm_ms = timed(args.warmup, args.steps, not args.no_profile, pwatch)
+    power = pwatch.summary()
+
+    # the rate the matrix pipes of THIS device sustain on the conv's bare MFMA stream, measured now, in this process
+    # (include/xsd.h: xsd_probe_mfma_stream): the roof the package power cap leaves of the nominal 2.5 PFLOP/s
+    sustained = None
+    if args.math in MATH_PRODUCTS and not args.no_sustained:
+        sustained = eng.probe_mfma_stream("f16" if args.math == "f16x3" else "bf16", args.sustained_seconds)
+
+    per_rank = None
+    if dp:      # what a < N x curve is made of: every rank's own step time, device clock and watts, exposed exchange wait
+        mine_rec = {"ms_per_step": round(1e3 * my_dt / args.steps, 3), "sclk_mhz": power["sclk_mhz"] if power else None,
+                    "avg_w": power["avg_w"] if power else None, "pci": my_pci,
+                    "comm_ms_exposed": None if comm_ms is None else round(comm_ms, 4),
+                    "sustained_mfma_tflops": None if sustained is None else round(sustained["mfma_tflops"], 1)}
+        recs = [None] * world
+        dist.all_gather_object(recs, mine_rec)
+        per_rank = {k: [r[k] for r in recs] for k in mine_rec}
 
     replicas_identical = None
     if dp and train:     # DDP invariant, checked outside the timed region: every rank holds bit-identical parameters
@@ -452,6 +538,11 @@ def main():
             hs = hc
         replicas_identical = all(bool(torch.equal(t.cpu(), hs[0].cpu())) for t in hs)
 
+    # ---- the second half of BASELINE's metric ("PSNR delta vs ref"), outside the timed region, in the mode the line is timed in
+    psnr_delta = None
+    if rank == 0 and NF == 32 and not args.no_psnr:
+        psnr_delta = psnr_delta_vs_reference(kind, args.math, dev)
+
     # ---- extra leg (same process, same inputs): another math mode over the same --steps/--warmup, labelled; never the headline
     extra = None
     xm = None if (args.no_extra or world > 1 or args.extra_math in ("none", args.math)) else args.extra_math   # N=1 only
@@ -462,15 +553,17 @@ def main():
         with torch.no_grad():
             y_x = model(x[:2])
         err = float((y_x - y_head).abs().max())
-        with PowerWatch(pci=pcis) as pwx:
-            dte, profe = timed(args.warmup, args.steps, not args.no_profile)
+        xm = eng.get_math()       # what the kernels really compute in (generic widths run exact fp32 whatever was asked for)
+        pwx = PowerWatch(pci=[my_pci] if my_pci else None)
+        dte, _, profe, _ = timed(args.warmup, args.steps, not args.no_profile, pwx)
         extra = {"math": xm, "dtype": MATHS[xm][0], "value": B * world * args.steps / dte, "unit": "tiles/s",
                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dte / args.steps,
                  "max_abs_output_diff_vs_" + args.math: err, "note": "not the headline: the strict mode, reported for comparison"}
         if pwx.summary() is not None:
             extra["power"] = pwx.summary()
         if profe is not None and profe[0]["launches"] > 0:
-            extra["roofline"] = roofline_block(xm, profe, B, kind, train, world, B * world * args.steps / dte, NF == 32)
+            xs = eng.probe_mfma_stream("f16" if xm == "f16x3" else "bf16", args.sustained_seconds) if (xm in MATH_PRODUCTS and not args.no_sustained) else None
+            extra["roofline"] = roofline_block(xm, profe, B, kind, train, world, B * world * args.steps / dte, NF == 32, xs)
         model.set_math(args.math)
 
     if rank == 0:
@@ -494,9 +587,15 @@ def main():
         if replicas_identical is not None:
             out["replicas_identical"] = replicas_identical
         if prof is not None and prof[0]["launches"] > 0:
-            out["roofline"] = roofline_block(args.math, prof, B, kind, train, world, tiles / dt, NF == 32)
+            out["roofline"] = roofline_block(args.math, prof, B, kind, train, world, tiles / dt, NF == 32, sustained)
         if power is not None:
             out["power"] = power
+        if train:
+            out["comm_ms_exposed"] = None if comm_ms is None else round(comm_ms, 4)     # rank 0's; every rank's in per_rank
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+        if psnr_delta is not None:
+            out.update(psnr_delta)
         if extra is not None:
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline and NF == 32:

@@ -165,6 +165,14 @@ int xsd_image_upsample(const float* dev_in, float* dev_out, int N, int H, int W,
 int xsd_profile_enable(xsd_engine* e, int enable);
 int xsd_profile_read(xsd_engine* e, int klass, double* total_ms, int64_t* launches, double* total_flop, double* total_bytes);
 
+/* What the matrix pipes of the current device SUSTAIN on the conv kernels' own MFMA stream (csrc/mfma_stream_probe.hip): eight
+ * waves per CU issuing the v_mfma_f32_32x32x16_{f16 (fmt 0), bf16 (fmt 1)} sequence of one conv half-step with its LDS fragment
+ * reads, on realistic split operands, no staging, no global traffic -- for `seconds` (0 < seconds <= 30) of back-to-back
+ * launches; reported over the second half (the package-power governor has settled by then): dense 16-bit MFMA TFLOP/s and the
+ * in-kernel shader clock in GHz (sclk_ghz may be NULL).  bench.py's `roofline.sustained_peak` = this rate / products per
+ * multiply, measured in the bench process on the bench's device.  Blocks the host until done. */
+int xsd_probe_mfma_stream(int fmt, double seconds, double* mfma_tflops, double* sclk_ghz, void* stream);
+
 /* Diagnostic only: accumulated shader-cycle stamps of the kernels' phases (32 slots; read with enable = 0).  Conv:
  * [0] prologue, [1] prefetch issue, [2] MFMA loop, [3] epilogue, [4] wait+barrier, [5] split+LDS write+barrier, [6] items,
  * [7] s_memrealtime ticks, [8..12] staging wave, [13..15] youngest MFMA wave; weight gradient: [16] staging rounds,

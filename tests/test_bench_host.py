@@ -22,8 +22,8 @@ def _fake_card(root, name, watts, mhz, cap=1400, pci=None):
 
 
 def test_power_watch_reads_the_busiest_device(tmp_path):
-    """bench.py's `power` block: sysfs hwmon files in microwatts / hertz, the busiest device wins, the first fifth of the
-    samples (ramp from idle) is dropped, the fraction of the cap is reported."""
+    """bench.py's `power` block: sysfs hwmon files in microwatts / hertz, the busiest device wins, every sample between
+    start() and stop() counts (bench.py starts the reader after the warm-up's synchronize), the fraction of the cap is reported."""
     import bench
     _fake_card(str(tmp_path), "card0", 240, 100)
     _fake_card(str(tmp_path), "card1", 1395, 1650)
@@ -32,6 +32,25 @@ def test_power_watch_reads_the_busiest_device(tmp_path):
     s = pw.summary()
     assert s is not None and s["cap_w"] == 1400.0 and abs(s["avg_w"] - 1395.0) < 0.5 and s["sclk_mhz"] == 1650.0
     assert abs(s["frac_of_cap"] - 1395.0 / 1400.0) < 1e-3 and s["samples"] >= 3
+    assert "first fifth" not in s["source"] and "warm-up" in s["source"]
+
+
+def test_power_watch_counts_only_samples_between_start_and_stop(tmp_path):
+    """an idle device before start() leaves no trace in the mean: the reader thread does not run until start()"""
+    import bench
+    pci = _fake_card(str(tmp_path), "card0", 200, 100)
+    pw = bench.PowerWatch(0.01, root=str(tmp_path))
+    time.sleep(0.1)                                          # 'engine creation + warm-up': not sampled
+    h = os.path.join(str(tmp_path), "_pci", pci, "hwmon", "hwmon0")
+    with open(os.path.join(h, "power1_input"), "w") as fh:
+        fh.write("%d\n" % int(1398e6))
+    pw.start()
+    time.sleep(0.2)
+    pw.stop()
+    n = pw.summary()["samples"]
+    time.sleep(0.05)
+    s = pw.summary()
+    assert s["samples"] == n and abs(s["avg_w"] - 1398.0) < 0.5
 
 
 def test_power_watch_without_devices_reports_nothing(tmp_path):

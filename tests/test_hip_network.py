@@ -258,7 +258,7 @@ def test_train_driver_overfits_fixed_batch_and_checkpoints(tmp_path):
     assert losses[-1] < 0.7 * losses[0]
     p = os.path.join(tmp_path, "last.ckpt")
     save_checkpoint(p, model, tr, epoch=0)
-    ck = torch.load(p, map_location="cpu", weights_only=False)
+    ck = torch.load(p, map_location="cpu", weights_only=True)
     assert "model.rrdb.0.RDB3.conv5.weight" in ck["state_dict"] and "model.conv_first.bias" in ck["state_dict"]
     m2 = Model(model_cfg("rrdb_denoise", batch_size=2, residual_blocks=1), (64, 64), (64, 64), None, None, None, None, None)
     load_checkpoint(p, m2)

@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Training trajectories of the DN generator in every math mode next to torch float64 / float32 of the same graph.
+
+What the reference does with this path is TRAIN it: hundreds of Adam steps of `Model._on_step` (models/model.py:72-86) under
+`configure_optimizers`' Adam(lr 1e-4, betas (0.9, 0.999)) (models/model.py:239-247; res/configs/models.toml:7-8).  One forward /
+backward parity says nothing about how a math mode's rounding accumulates over such a run, so this script runs it:
+
+  * net: GeneratorRRDB_DN(1, 1, 32, 4) -- the shipped width and depth -- reference-default init under torch.manual_seed(0);
+  * data: a fixed batch of 4 denoising pairs (smooth fields + noise -> the clean field, clipped to [0, 1] so the clamp and its
+    ties take part), tiles of `size` x `size`; 2 held-out pairs from other seeds;
+  * `steps` steps of mean-L1 + Adam(1e-4) from the SAME start in
+      engine f16x3 / bf16x6 / fp32                   (DataParallelTrainer.train_step: the HIP kernels, the fused Adam kernel)
+      torch float64, torch float32 on the GPU        (oracle.torch_forward + autograd + torch.optim.Adam: the yard-sticks;
+                                                      float32 here = MIOpen's fp32 convolutions)
+      torch float32 on the host cores (optional)     (oneDNN's fp32 convolutions: a second, independent fp32 yard-stick);
+  * recorded: the loss of every step, PSNR of the two held-out tiles at the checkpoints (default 50 / 100 / 200).
+
+The bar (tests/test_hip_trajectory.py asserts it; VERDICT round 4, Next 1): at every checkpoint, for f16x3 and for bf16x6,
+  |loss - loss_f64| and |PSNR - PSNR_f64|  <=  2 x the same distance of torch float32 (the larger of its yard-sticks, and
+  never less than one float32 ulp of the quantity: a yard-stick that happens to land ON float64 must not turn the bar into 0),
+  and |PSNR - PSNR_f64| <= 0.01 dB at the last checkpoint.
+
+Run on the GPU box: `python tools/trajectory.py [--steps 200] [--size 96] [--out profiles/r05_trajectory.txt]`.
+oracle/ is used here as the yard-stick (a tool and a test, never the product path)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "xmm-superres-denoise_amd"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+ENGINE_MODES = ("f16x3", "bf16x6", "fp32")
+NF, BLOCKS = 32, 4
+LR, BETAS = 1e-4, (0.9, 0.999)
+
+
+def denoise_pairs(n, size, seed):
+    """n (noisy, clean) pairs [n,1,size,size] float32 in [0,1]: a smooth field with a few point sources, Gaussian noise on the
+    input.  Values are clipped, so exact 0 / 1 ties exist on both sides (clamped outputs meet them)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float64)
+    clean = np.empty((n, 1, size, size), np.float64)
+    for b in range(n):
+        f = 0.35 + 0.3 * np.sin(xx / (7.0 + 1.3 * b) + 0.7 * b + seed) * np.cos(yy / (5.0 + 0.9 * b) - seed)
+        for _ in range(6):     # point sources with a Gaussian profile (what an EPIC-pn tile holds)
+            cx, cy, a, s = rng.uniform(0, size), rng.uniform(0, size), rng.uniform(0.3, 0.9), rng.uniform(1.2, 3.0)
+            f = f + a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+        clean[b, 0] = f
+    clean = np.clip(clean, 0, 1)
+    noisy = np.clip(clean + 0.12 * rng.standard_normal(clean.shape), 0, 1)
+    return noisy.astype(np.float32), clean.astype(np.float32)
+
+
+def psnr_db(pred, target):
+    """10 log10(1 / mse) in float64, per tile ([n,1,H,W] -> n values); data range 1"""
+    import torch
+    mse = ((pred.double() - target.double()) ** 2).mean(dim=(1, 2, 3))
+    return (-10.0 * torch.log10(mse)).tolist()
+
+
+def start_state():
+    """reference-default init (generator_rrdb.py:56-64 + torch's Conv2d default) under torch.manual_seed(0), as float32 CPU tensors"""
+    import torch
+    from xmm_superres_denoise.models import GeneratorRRDB_DN
+    torch.manual_seed(0)
+    m = GeneratorRRDB_DN(1, 1, NF, BLOCKS)
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def run_engine(mode, state, x, t, xh, th, steps, checkpoints, device="cuda"):
+    import torch
+    from xmm_superres_denoise.models import GeneratorRRDB_DN
+    from xmm_superres_denoise.parallel import DataParallelTrainer
+    m = GeneratorRRDB_DN(1, 1, NF, BLOCKS)
+    m.load_state_dict({k: v.clone() for k, v in state.items()})
+    m = m.to(device)
+    m.set_math(mode)
+    tr = DataParallelTrainer(m, lr=LR, betas=BETAS)
+    xd, td, xhd, thd = (torch.from_numpy(a).to(device) for a in (x, t, xh, th))
+    losses, ck = [], {}
+    for s in range(1, steps + 1):
+        losses.append(tr.train_step(xd, td))          # device scalars: no host sync inside the loop
+        if s in checkpoints:
+            with torch.no_grad():
+                ck[s] = psnr_db(m(xhd), thd)
+    return [float(v) for v in torch.stack(losses).double().cpu()], ck
+
+
+def run_torch(dtype_name, state, x, t, xh, th, steps, checkpoints, device="cuda"):
+    """the same graph, loss and optimizer in torch (oracle.torch_forward: the restatement the goldens pin to the reference)"""
+    import torch
+    from oracle import oracle
+    dt = {"float64": torch.float64, "float32": torch.float32}[dtype_name]
+    if device == "cpu":
+        torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    # clone: .to() of a float32 CPU tensor to float32 CPU is the tensor itself, and Adam updates in place
+    st = {k: v.detach().clone().to(device=device, dtype=dt).requires_grad_(True) for k, v in state.items()}
+    opt = torch.optim.Adam(list(st.values()), lr=LR, betas=BETAS, eps=1e-8)
+    xd, td, xhd, thd = (torch.from_numpy(a).to(device=device, dtype=dt) for a in (x, t, xh, th))
+    losses, ck = [], {}
+    for s in range(1, steps + 1):
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.l1_loss(oracle.torch_forward("dn", NF, BLOCKS, st, xd), td)
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+        if s in checkpoints:
+            with torch.no_grad():
+                ck[s] = psnr_db(oracle.torch_forward("dn", NF, BLOCKS, st, xhd), thd)
+    return [float(v) for v in torch.stack(losses).double().cpu()], ck
+
+
+def run_all(steps=200, size=96, checkpoints=(50, 100, 200), cpu_f32=False, log=print):
+    """-> {leg: (losses, {checkpoint: [psnr tile 0, psnr tile 1]})}; legs: the three engine modes, 'float64', 'float32' (GPU),
+    and 'float32_cpu' when asked for"""
+    checkpoints = tuple(c for c in checkpoints if c <= steps)
+    state = start_state()
+    x, t = denoise_pairs(4, size, 11)
+    xh, th = denoise_pairs(2, size, 23)
+    out = {}
+    legs = [("float64", lambda: run_torch("float64", state, x, t, xh, th, steps, checkpoints)),
+            ("float32", lambda: run_torch("float32", state, x, t, xh, th, steps, checkpoints))]
+    if cpu_f32:
+        legs.append(("float32_cpu", lambda: run_torch("float32", state, x, t, xh, th, steps, checkpoints, device="cpu")))
+    legs += [(m, (lambda m=m: run_engine(m, state, x, t, xh, th, steps, checkpoints))) for m in ENGINE_MODES]
+    import torch
+    start = {k: v.clone() for k, v in state.items()}
+    for name, fn in legs:
+        t0 = time.perf_counter()
+        out[name] = fn()
+        assert all(torch.equal(state[k], start[k]) for k in state), f"leg {name} modified the shared start state"
+        log(f"# {name}: {steps} steps in {time.perf_counter() - t0:.1f} s, loss {out[name][0][0]:.6f} -> {out[name][0][-1]:.6f}")
+    return out, checkpoints
+
+
+F32_ULP = 2.0 ** -23
+
+
+def verdict(res, checkpoints):
+    """rows (leg, checkpoint, |dloss|, |dpsnr| worst tile, yard |dloss|, yard |dpsnr|, ok) for the engine modes; the yard-stick is
+    the larger float32 distance to float64, floored at one float32 ulp of the quantity"""
+    ref_l, ref_p = res["float64"]
+    yards = [k for k in ("float32", "float32_cpu") if k in res]
+    rows = []
+    for leg in ENGINE_MODES:
+        if leg not in res:
+            continue
+        for c in checkpoints:
+            dl = abs(res[leg][0][c - 1] - ref_l[c - 1])
+            dp = max(abs(a - b) for a, b in zip(res[leg][1][c], ref_p[c]))
+            yl = max(max(abs(res[y][0][c - 1] - ref_l[c - 1]) for y in yards), F32_ULP * abs(ref_l[c - 1]))
+            yp = max(max(max(abs(a - b) for a, b in zip(res[y][1][c], ref_p[c])) for y in yards), F32_ULP * max(ref_p[c]))
+            ok = dl <= 2 * yl and dp <= 2 * yp and (c != checkpoints[-1] or dp <= 0.01)
+            rows.append((leg, c, dl, dp, yl, yp, ok))
+    return rows
+
+
+def report(res, checkpoints, steps, size):
+    ref_l, ref_p = res["float64"]
+    lines = [f"DN 32 filters x 4 blocks, 4 tiles of {size}x{size}, mean-L1 + Adam(lr 1e-4, betas (0.9, 0.999)), {steps} steps from the "
+             "reference-default init (seed 0); 2 held-out tiles",
+             "",
+             "loss at step          " + "".join(f"{c:>14d}" for c in (1,) + tuple(checkpoints)),
+             ]
+    for leg in res:
+        lines.append(f"  {leg:<20s}" + "".join(f"{res[leg][0][c - 1]:14.8f}" for c in (1,) + tuple(checkpoints)))
+    lines += ["", "|loss - loss_float64|  " + "".join(f"{c:>14d}" for c in (1,) + tuple(checkpoints))]
+    for leg in res:
+        if leg != "float64":
+            lines.append(f"  {leg:<20s}" + "".join(f"{abs(res[leg][0][c - 1] - ref_l[c - 1]):14.3e}" for c in (1,) + tuple(checkpoints)))
+    lines += ["", "largest |loss - loss_float64| over all steps, and the step it occurs at"]
+    for leg in res:
+        if leg != "float64":
+            d = np.abs(np.array(res[leg][0]) - np.array(ref_l))
+            lines.append(f"  {leg:<20s}{d.max():14.3e}   step {int(d.argmax()) + 1}")
+    lines += ["", "PSNR (dB) of the held-out tiles at step" + "".join(f"{c:>22d}" for c in checkpoints)]
+    for leg in res:
+        lines.append(f"  {leg:<20s}                " + "".join(f"   {res[leg][1][c][0]:9.5f} {res[leg][1][c][1]:9.5f}" for c in checkpoints))
+    lines += ["", "|PSNR - PSNR_float64| (dB), worst tile" + "".join(f"{c:>14d}" for c in checkpoints)]
+    for leg in res:
+        if leg != "float64":
+            lines.append(f"  {leg:<20s}                " + "".join(
+                f"{max(abs(a - b) for a, b in zip(res[leg][1][c], ref_p[c])):14.3e}" for c in checkpoints))
+    rows = verdict(res, checkpoints)
+    lines += ["", "bar: |dloss| <= 2 x float32's, |dPSNR| <= 2 x float32's at every checkpoint; |dPSNR| <= 0.01 dB at the last",
+              f"  {'mode':<8s}{'step':>6s}{'|dloss|':>12s}{'2 x yard':>12s}{'|dPSNR|':>12s}{'2 x yard':>12s}   ok"]
+    for leg, c, dl, dp, yl, yp, ok in rows:
+        lines.append(f"  {leg:<8s}{c:6d}{dl:12.3e}{2 * yl:12.3e}{dp:12.3e}{2 * yp:12.3e}   {'yes' if ok else 'NO'}")
+    lines.append("")
+    lines.append("ALL WITHIN THE BAR" if all(r[-1] for r in rows) else "BAR MISSED: " + ", ".join(f"{r[0]}@{r[1]}" for r in rows if not r[-1]))
+    return "\n".join(lines), rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--size", type=int, default=96)
+    ap.add_argument("--checkpoints", default="50,100,200")
+    ap.add_argument("--cpu-f32", action="store_true", help="also run torch float32 on the host cores (oneDNN) as a second yard-stick")
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    cps = tuple(int(c) for c in a.checkpoints.split(","))
+    res, cps = run_all(a.steps, a.size, cps, a.cpu_f32)
+    text, rows = report(res, cps, a.steps, a.size)
+    print(text)
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        with open(a.out, "w") as f:
+            f.write(text + "\n\nloss per step (step, " + ", ".join(res) + ")\n")
+            for s in range(a.steps):
+                f.write(f"{s + 1:4d} " + " ".join(f"{res[k][0][s]:.9f}" for k in res) + "\n")
+    return 0 if all(r[-1] for r in rows) else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -35,6 +35,7 @@ using namespace xsd;
 namespace xsd {
 int debug_conv_occupancy(int lds_bytes);
 float debug_residency_ms(int grid, int threads, int lds_bytes, int us);
+hipError_t probe_mfma_stream(int fmt, double seconds, double* mfma_tflops, double* sclk_ghz, hipStream_t stream);
 hipError_t launch_pack_shuffle_bias(const float* b, float* out, int planes, hipStream_t s);
 }
 
@@ -1490,6 +1491,14 @@ int xsd_image_upsample(const float* dev_in, float* dev_out, int N, int H, int W,
 
 int xsd_debug_occupancy(int lds_bytes) { return xsd::debug_conv_occupancy(lds_bytes); }
 float xsd_debug_residency_ms(int grid, int threads, int lds_bytes, int us) { return xsd::debug_residency_ms(grid, threads, lds_bytes, us); }
+
+int xsd_probe_mfma_stream(int fmt, double seconds, double* mfma_tflops, double* sclk_ghz, void* stream)
+{
+    if ((fmt != 0 && fmt != 1) || !(seconds > 0.0) || seconds > 30.0 || !mfma_tflops)
+        return fail(XSD_ERR_ARG, "xsd_probe_mfma_stream: fmt must be 0 (f16) or 1 (bf16), 0 < seconds <= 30, mfma_tflops non-NULL");
+    HIPCHK(xsd::probe_mfma_stream(fmt, seconds, mfma_tflops, sclk_ghz, (hipStream_t)stream));
+    return XSD_OK;
+}
 
 // diagnostic: accumulate shader-cycle stamps of the conv kernel's phases (enable != 0 allocates/zeroes; read copies out)
 int xsd_debug_stamps(xsd_engine* e, int enable, unsigned long long* out16)

@@ -69,6 +69,7 @@ def load():
     L.xsd_debug_stamps.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64)]
     L.xsd_profile_read.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64),
                                    ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    L.xsd_probe_mfma_stream.argtypes = [i32, ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), vp]
     L.xsd_test_conv3x3.argtypes = [vp, ctypes.POINTER(vp), i32, fp, fp, ctypes.POINTER(vp), i32, f32, i32, i32, i32, vp]
     L.xsd_test_conv3x3_bwd.argtypes = [vp, ctypes.POINTER(vp), i32, fp, fp, ctypes.POINTER(vp), fp, fp, i32, i32, i32, vp]
     _lib = L
@@ -80,7 +81,7 @@ ABI_SYMBOLS = [
     "xsd_last_error", "xsd_version", "xsd_create", "xsd_destroy", "xsd_param_count", "xsd_set_math", "xsd_get_math", "xsd_pack_weights",
     "xsd_forward", "xsd_backward", "xsd_backward_num_stages", "xsd_backward_stage", "xsd_grad_range",
     "xsd_l1_loss", "xsd_loss_create", "xsd_loss_destroy", "xsd_loss_eval", "xsd_adam_step", "xsd_mask_pad_normalize", "xsd_compose_input", "xsd_normalize", "xsd_image_upsample",
-    "xsd_profile_enable", "xsd_profile_read", "xsd_debug_stamps", "xsd_debug_occupancy", "xsd_debug_residency_ms", "xsd_test_conv3x3", "xsd_test_conv3x3_bwd",
+    "xsd_profile_enable", "xsd_profile_read", "xsd_probe_mfma_stream", "xsd_debug_stamps", "xsd_debug_occupancy", "xsd_debug_residency_ms", "xsd_test_conv3x3", "xsd_test_conv3x3_bwd",
 ]
 
 

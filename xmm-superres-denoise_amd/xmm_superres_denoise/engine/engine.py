@@ -163,6 +163,14 @@ class Engine:
         check(self.L.xsd_profile_read(self.h, klass, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by)))
         return {"ms": ms.value, "launches": n.value, "flop": fl.value, "bytes": by.value}
 
+    def probe_mfma_stream(self, fmt: str = "f16", seconds: float = 2.0):
+        """dense 16-bit MFMA TFLOP/s and in-kernel clock the current device sustains on the conv's bare MFMA-wave stream
+        (include/xsd.h: xsd_probe_mfma_stream); blocks for about `seconds`"""
+        tf, gz = ctypes.c_double(), ctypes.c_double()
+        check(self.L.xsd_probe_mfma_stream({"f16": 0, "bf16": 1}[fmt], float(seconds), ctypes.byref(tf), ctypes.byref(gz),
+                                           _stream_ptr(torch.device("cuda", torch.cuda.current_device()))))
+        return {"mfma_tflops": tf.value, "sclk_ghz": gz.value, "seconds": float(seconds), "fmt": fmt}
+
 
 # ---- stateless transform entry points --------------------------------------------------------------------------
 def mask_pad_normalize(counts: torch.Tensor, mask: torch.Tensor | None, res: int, max_val: float | None,

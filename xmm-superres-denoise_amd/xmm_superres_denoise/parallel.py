@@ -68,6 +68,7 @@ class DataParallelTrainer:
         # and are reduced as CPU tensors; RCCL ("nccl") reduces in place on the device, asynchronously.
         self._host = None
         self._copy_stream = None
+        self._comm_events = None      # measurement (bench.py): [(before, after)] event pairs around the wait for the exchange
         if self.distributed:
             # replicas must start identical (DDP broadcasts rank 0's parameters at construction)
             if dist.get_backend(process_group) == "gloo" and self.flat.is_cuda:
@@ -133,15 +134,36 @@ class DataParallelTrainer:
         for landed, off, cnt in staged:          # gloo: stage s is reduced on the host while the device still computes stages > s
             landed.synchronize()
             works.append((dist.all_reduce(self._host[off:off + cnt], op=dist.ReduceOp.SUM, group=self.pg, async_op=True), (off, cnt)))
+        # Exposed communication = what the compute stream spends between its last backward kernel and Adam.  Under RCCL
+        # `wait()` does not block the host: it makes the current stream wait for RCCL's; under gloo the host blocks and the
+        # copies back are enqueued afterwards.  Either way an event pair on the compute stream around this loop measures it.
+        ev = None
+        if self._comm_events is not None and self.distributed:
+            cur = torch.cuda.current_stream(self.grads.device)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(cur)
         for w, back in works:
             w.wait()
             if back is not None:
                 off, cnt = back
                 self.grads[off:off + cnt].copy_(self._host[off:off + cnt], non_blocking=True)
+        if ev is not None:
+            ev[1].record(cur)
+            self._comm_events.append(ev)
         self.step_count += 1
         eng.adam_step(self.flat, self.grads, self.m, self.v, self.step_count, self.lr, self.betas, self.eps,
                       grad_scale=1.0 / self.world)
         return loss
+
+    def comm_events_begin(self):
+        """start recording one event pair per train step around the wait for the gradient exchange (bench.py: comm_ms_exposed)"""
+        self._comm_events = []
+
+    def comm_events_end(self) -> float:
+        """total milliseconds the compute stream spent waiting for the exchange since comm_events_begin (0.0 without a process
+        group: there is no exchange); call after a device synchronize"""
+        evs, self._comm_events = self._comm_events or [], None
+        return float(sum(a.elapsed_time(b) for a, b in evs))
 
     def global_loss(self, local_loss: torch.Tensor) -> torch.Tensor:
         """Mean of the per-rank mean losses (what `sync_dist=True` logging reports, models/model.py:118)."""

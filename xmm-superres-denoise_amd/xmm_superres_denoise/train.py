@@ -29,7 +29,11 @@ def save_checkpoint(path: str, model: Model, trainer: DataParallelTrainer, epoch
 
 
 def load_checkpoint(path: str, model: Model, trainer: DataParallelTrainer | None = None) -> dict:
-    ck = torch.load(path, map_location="cpu", weights_only=False)
+    """Reads a checkpoint with the loader that executes nothing from the file (`weights_only=True`: tensors, numbers, strings,
+    dicts / lists of them).  What save_checkpoint writes is exactly that; a Lightning `.ckpt` carrying pickled objects
+    (callback states, hyper-parameter namespaces) is refused with torch's UnpicklingError rather than unpickled -- strip it
+    to {"state_dict": ...} with a trusted tool first."""
+    ck = torch.load(path, map_location="cpu", weights_only=True)
     sd = {k[len("model."):]: v for k, v in ck["state_dict"].items() if k.startswith("model.")}
     if model.model is None:
         model.configure_model()
