@@ -76,6 +76,13 @@ int64_t xsd_param_count(const xsd_engine* e);
  * (Modes 1 and 2 -- two-term bf16 splits with 16-bit significands -- existed in rounds 1-2 and were removed.)
  * Default: 4 (f16x3), or the environment variable XSD_MATH ("fp32" | "bf16x6" | "f16x3"; anything else fails xsd_create).
  * Changing it invalidates the packed weights and the plan.
+ * Other environment variables the production library reads (each once per process; results are identical to rounding either way):
+ *   XSD_WGRAD_BLOCK=0   the weight gradients of a dense block as one launch per G (five launches) instead of ONE pair-list launch
+ *                       over its 15 (X, G) pairs (default 1; A/B switch, tools/ab_env.sh; tests hold the two forms to 2e-6);
+ *   XSD_WGRAD_TAIL=0    no extra part on the CUs the block launch's 8 m x 15 workgroups leave (default 1; MI355X: a 17th part);
+ *   XSD_TEST_NCU=n      TEST HOOK: plan the block launch as if the device had n compute units (n < 120: one launch per G);
+ *   XSD_TEST_AMAX_CAP=n TEST HOOK: initial capacity of the max-|x| slot array (default 65536 floats), so that a small net
+ *                       exercises the grow / copy / rebuild path a 256-filter x 64-block net would take.
  * Modes 3 and 4 address a plane's batch slice with 32-bit byte offsets: images of 2^24 or more output pixels are rejected
  * by xsd_forward (mode 0 takes them). */
 int xsd_set_math(xsd_engine* e, int mode);
@@ -102,6 +109,7 @@ int xsd_backward(xsd_engine* e, const float* dev_dy, float* dev_dx_or_null, floa
  * stage 0 (output head + trunk_conv), stages 1..blocks (RRDB blocks-1 .. 0), stage blocks+1 (conv_first).
  * After stage s returns, the gradient ranges reported by xsd_grad_range(stage) are final on the stream, so the caller
  * can start their all-reduce on a side stream while later stages run. */
+/* Several backwards after ONE forward (different dy) are allowed: stage 0 resets what the previous backward left. */
 int xsd_backward_num_stages(const xsd_engine* e);
 int xsd_backward_stage(xsd_engine* e, int stage, const float* dev_dy, float* dev_dx_or_null, float* dev_grads, void* stream);
 int xsd_grad_range(const xsd_engine* e, int stage, int range_idx, int64_t* offset, int64_t* count); /* returns number of ranges */

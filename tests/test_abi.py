@@ -150,3 +150,18 @@ def test_bench_contract_without_gpu():
             mock.patch.object(sys, "argv", ["bench.py", "--gpus", "4"]):
         with pytest.raises(SystemExit, match="does not match"):
             bench.main()
+
+
+def test_library_holds_only_the_adopted_conv_kernel_instances():
+    """csrc/conv3x3_h2x.hip: X3_KINDS names the epilogue kinds that run on their own kernel instance; the others are not
+    instantiated at all (no dead device code in the shipped library)."""
+    import re
+    import subprocess
+    from xmm_superres_denoise.engine import _lib
+    src = open(os.path.join(_lib.CSRC_DIR, "conv3x3_h2x.hip")).read()
+    kinds_mask = int(re.search(r"#define X3_KINDS (\d+)", src).group(1))
+    kind_list = [int(v) for v in re.search(r"X3_KIND_LIST\[7\] = \{([^}]*)\}", src).group(1).split(",")]
+    adopted = {k for i, k in enumerate(kind_list) if (kinds_mask >> i) & 1}
+    syms = subprocess.run(["nm", "-C", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    built = {int(m) for m in re.findall(r"__device_stub__conv3x3_h2x_kind_kernel<(\d+)>", syms)}
+    assert built == adopted, (built, adopted)

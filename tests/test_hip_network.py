@@ -493,16 +493,90 @@ def test_block_weight_gradient_launch_equals_one_launch_per_g(tmp_path, math):
         "g = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()}\n"
         "g['dx'] = x.grad.detach().cpu().numpy()\n"
         "np.savez(sys.argv[2], **g)\n")
-    outs = []
-    for sw in ("1", "0"):
-        out = str(tmp_path / f"g{sw}.npz")
-        env = dict(os.environ, XSD_WGRAD_BLOCK=sw)
+    # variants (include/xsd.h): the default (MI355X: 16 parts + a 17th on the spare CUs), one launch per G, no tail part, and the
+    # plans of devices with other CU counts (XSD_TEST_NCU: 128 CUs -> 8 parts, no tail; 140 -> 8 parts + tail; 100 -> fewer than
+    # one part per XCD: falls back to one launch per G).  Every cut of the tiles into partial sums must give the same gradient.
+    variants = {"default": {}, "per_g": {"XSD_WGRAD_BLOCK": "0"}, "no_tail": {"XSD_WGRAD_TAIL": "0"},
+                "ncu128": {"XSD_TEST_NCU": "128"}, "ncu140": {"XSD_TEST_NCU": "140"}, "ncu100": {"XSD_TEST_NCU": "100"}}
+    outs = {}
+    for name, extra in variants.items():
+        out = str(tmp_path / f"g_{name}.npz")
+        env = {k: v for k, v in os.environ.items() if k not in ("XSD_WGRAD_BLOCK", "XSD_WGRAD_TAIL", "XSD_TEST_NCU")}
+        env.update(extra)
         p = subprocess.run([sys.executable, "-c", code, root, out, math], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert p.returncode == 0, (name, p.stdout.decode(errors="replace")[-3000:])
+        outs[name] = np.load(out)
+    b = outs["per_g"]
+    for name, a in outs.items():
+        assert set(a.files) == set(b.files)
+        for k in a.files:
+            ref = np.abs(b[k]).max() + 1e-30
+            assert np.abs(a[k] - b[k]).max() / ref < 2e-6, (name, k, float(np.abs(a[k] - b[k]).max() / ref))
+        assert np.array_equal(a["dx"], b["dx"])      # the input gradient does not depend on the weight-gradient launches at all
+    # a device with fewer than 120 CUs takes the per-G path: bit-equal to XSD_WGRAD_BLOCK=0; the differently cut launches are not
+    for k in b.files:
+        assert np.array_equal(outs["ncu100"][k], b[k]), k
+    assert any(not np.array_equal(outs["default"][k], b[k]) for k in b.files)
+    assert any(not np.array_equal(outs["no_tail"][k], outs["default"][k]) for k in b.files)
+    assert any(not np.array_equal(outs["ncu128"][k], outs["default"][k]) for k in b.files)
+
+
+def test_max_abs_slot_array_grows_without_changing_results(tmp_path):
+    """f16x3 scales every operand tensor from a max-|x| slot; the slot array grows (synchronize, reallocate, copy the packed
+    panels' two slots, rebuild the plan) when the sizing pass counts more slots than are allocated -- 65,536 by default, i.e.
+    only for nets like 256 filters x 64 blocks.  XSD_TEST_AMAX_CAP=128 (include/xsd.h) makes the 4-block shipped net take that
+    path, twice over (forward-only plan, then the training plan): outputs and gradients bit-equal to the default capacity."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        "root = sys.argv[1]\n"
+        "for p in (root, os.path.join(root, 'xmm-superres-denoise_amd'), os.path.join(root, 'tests'), os.path.join(root, 'tests', 'golden')): sys.path.insert(0, p)\n"
+        "from xmm_superres_denoise.models import GeneratorRRDB_DN\n"
+        "torch.manual_seed(9)\n"
+        "m = GeneratorRRDB_DN(1, 1, 32, 4).cuda().set_math('f16x3')\n"
+        "x = torch.rand(2, 1, 40, 72, device='cuda'); t = torch.rand(2, 1, 40, 72, device='cuda')\n"
+        "with torch.no_grad(): y0 = m(x).cpu().numpy()\n"
+        "xg = x.clone().requires_grad_(True)\n"
+        "y = m(xg); loss = (y - t).abs().mean(); loss.backward()\n"
+        "g = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()}\n"
+        "g['dx'] = xg.grad.detach().cpu().numpy(); g['y0'] = y0; g['y'] = y.detach().cpu().numpy()\n"
+        "np.savez(sys.argv[2], **g)\n")
+    outs = []
+    for cap in (None, "128"):
+        out = str(tmp_path / f"cap_{cap}.npz")
+        env = {k: v for k, v in os.environ.items() if k != "XSD_TEST_AMAX_CAP"}
+        if cap:
+            env["XSD_TEST_AMAX_CAP"] = cap
+        p = subprocess.run([sys.executable, "-c", code, root, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
         outs.append(np.load(out))
     a, b = outs
-    assert set(a.files) == set(b.files)
+    assert np.abs(a["y"]).max() > 0 and np.abs(a["conv_first.weight"]).max() > 0
     for k in a.files:
-        ref = np.abs(b[k]).max() + 1e-30
-        assert np.abs(a[k] - b[k]).max() / ref < 2e-6, (k, float(np.abs(a[k] - b[k]).max() / ref))
-    assert np.array_equal(a["dx"], b["dx"])      # the input gradient does not depend on the weight-gradient launches at all
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_second_backward_after_one_forward_starts_from_clean_max_slots():
+    """Two backwards after ONE forward with different dy (include/xsd.h: allowed).  The backward launches publish their planes'
+    max |x| by atomic max into slots that stage 0 re-zeroes: the second backward's gradients are bit-equal to those of a fresh
+    forward + backward with that dy -- also when the first dy was 2^20 times larger (stale maxima would have cost f16x3
+    twenty operand bits, not an overflow)."""
+    state = gc.make_state("dn", 32, 2, 31)
+    m = build_module("dn", 2, 1, state).set_math("f16x3")
+    eng = m._get_engine(torch.device("cuda", 0))
+    flat = m.flat_parameters()
+    x = torch.from_numpy(gc.make_input((2, 1, 40, 56), 32)).cuda()
+    dy_small = torch.from_numpy(gc.make_input((2, 1, 40, 56), 33) - 0.5).cuda().contiguous()
+    dy_big = (dy_small * 2.0 ** 20).contiguous()
+    eng.pack(flat)
+    g_ref = torch.empty_like(flat)
+    eng.forward(x, save_for_backward=True)
+    dx_ref = eng.backward(dy_small, g_ref, need_dx=True)
+    g1, g2 = torch.empty_like(flat), torch.empty_like(flat)
+    eng.forward(x, save_for_backward=True)
+    eng.backward(dy_big, g1, need_dx=True)
+    dx2 = eng.backward(dy_small, g2, need_dx=True)
+    assert torch.equal(g2, g_ref) and torch.equal(dx2, dx_ref)
+    assert float(g1.abs().max()) > 1e3 * float(g_ref.abs().max())

@@ -14,22 +14,24 @@ pytestmark = pytest.mark.gpu
 
 
 def test_training_trajectory_every_math_mode_vs_float64():
-    """DN 32 x 4, fixed batch of 4 tiles of 96 x 96, seeded reference init, 200 steps of L1 + Adam(1e-4).  At steps 50 / 100 /
-    200 the engine's loss and the PSNR of two held-out tiles sit within 2 x torch-float32's own distance to float64 (float32 on
-    the GPU = MIOpen and on the host = oneDNN: the larger of the two), and within 0.01 dB at step 200 -- for f16x3 (the
-    headline mode) and for bf16x6 / fp32 alike."""
+    """DN 32 x 4, fixed batch of 4 tiles of 64 x 64, seeded reference init, 200 steps of L1 + Adam(1e-4).  The optimisation is
+    chaotic at the 0.02 - 0.35 dB level for EVERY fp32 arithmetic, torch's included (tools/trajectory.py, profiles/
+    r05_trajectory.txt), so the bar is relative: at steps 50 / 100 / 200 the engine's loss and the PSNR of two held-out tiles
+    sit within 2 x the largest distance to the float64 run among the deterministic yard-sticks -- torch float32 on the host cores
+    (oneDNN) and three float64 runs whose start weights are moved by at most one fp32 ulp -- for f16x3 (the headline mode), bf16x6
+    and fp32 alike.  Everything in the bar is deterministic (the engine is bitwise reproducible; MIOpen's float32 is not, and is
+    only printed)."""
     import trajectory as tj
     assert torch.cuda.is_available()
-    res, cps = tj.run_all(steps=200, size=96, checkpoints=(50, 100, 200), cpu_f32=True, log=lambda s: print(s, flush=True))
-    text, rows = tj.report(res, cps, 200, 96)
+    res, cps = tj.run_all(steps=200, size=64, checkpoints=(50, 100, 200), cpu_f32=True, members=3, gpu_f32=True, log=lambda s: print(s, flush=True))
+    text, rows = tj.report(res, cps, 200, 64)
     print(text)
     # the run is a real optimisation: the loss falls by more than a third and every leg agrees on that
     for leg, (losses, _) in res.items():
         assert losses[-1] < 0.67 * losses[0], (leg, losses[0], losses[-1])
+    # step 1 is one forward from identical weights: every engine mode within 1e-6 of float64's loss
+    for leg in tj.ENGINE_MODES:
+        assert abs(res[leg][0][0] - res["float64"][0][0]) < 1e-6 * res["float64"][0][0] + 1e-7, leg
     assert {r[0] for r in rows} == set(tj.ENGINE_MODES)
     bad = [r for r in rows if not r[-1]]
     assert not bad, bad
-    # absolute statement beside the relative one: every mode's PSNR at step 200 within 0.01 dB of float64's
-    for leg in tj.ENGINE_MODES:
-        d = max(abs(a - b) for a, b in zip(res[leg][1][cps[-1]], res["float64"][1][cps[-1]]))
-        assert d <= 0.01, (leg, d)

@@ -91,6 +91,11 @@ def main():
     if "RANK" in os.environ:
         return worker()
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    if world > 3:
+        # profiles/r04_gloo_cuda_probe.txt: with four processes on ONE device the probe finished no iteration in 150 s and had to be
+        # killed mid-collective on the GPU.  That result is on record; reproducing it means leaving hung GPU work behind.
+        sys.exit("gloo_cuda_probe: refusing N > 3 ranks on one GPU (the 4-rank stall is recorded in profiles/r04_gloo_cuda_probe.txt; "
+                 "do not re-run it to reproduce the hang)")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

@@ -10,15 +10,23 @@ backward parity says nothing about how a math mode's rounding accumulates over s
     ties take part), tiles of `size` x `size`; 2 held-out pairs from other seeds;
   * `steps` steps of mean-L1 + Adam(1e-4) from the SAME start in
       engine f16x3 / bf16x6 / fp32                   (DataParallelTrainer.train_step: the HIP kernels, the fused Adam kernel)
-      torch float64, torch float32 on the GPU        (oracle.torch_forward + autograd + torch.optim.Adam: the yard-sticks;
-                                                      float32 here = MIOpen's fp32 convolutions)
-      torch float32 on the host cores (optional)     (oneDNN's fp32 convolutions: a second, independent fp32 yard-stick);
+      torch float64 on the GPU                       (oracle.torch_forward + autograd + torch.optim.Adam: the reference run)
+      torch float32 on the host cores                (oneDNN's fp32 convolutions: the fp32 yard-stick; deterministic)
+      torch float32 on the GPU                       (MIOpen's fp32 convolutions: reported, NOT part of the bar -- its result
+                                                      differs from run to run: 29.42 and 29.86 dB on the same device, same inputs)
+      torch float64 from a start moved by <= 1 fp32 ulp per weight (`members` seeded runs, w (1 + d 2^-23), d in {-1, 0, 1}):
+                                                     exact arithmetic, equivalent start -- what the TRAJECTORY ITSELF does with
+                                                     a perturbation of the size of one fp32 rounding;
   * recorded: the loss of every step, PSNR of the two held-out tiles at the checkpoints (default 50 / 100 / 200).
 
-The bar (tests/test_hip_trajectory.py asserts it; VERDICT round 4, Next 1): at every checkpoint, for f16x3 and for bf16x6,
-  |loss - loss_f64| and |PSNR - PSNR_f64|  <=  2 x the same distance of torch float32 (the larger of its yard-sticks, and
-  never less than one float32 ulp of the quantity: a yard-stick that happens to land ON float64 must not turn the bar into 0),
-  and |PSNR - PSNR_f64| <= 0.01 dB at the last checkpoint.
+What the first runs showed (profiles/r05_trajectory.txt): this optimisation is chaotic at the 0.02 - 0.35 dB level.  Every
+fp32-class run -- torch's own two float32 paths, the exact-fp32 MFMA mode, the exact bf16x6 split, f16x3 -- and every
+ulp-perturbed float64 run ends 0.02 - 0.3 dB from the float64 run at step 200 and up to 0.35 dB around step 100, where the
+loss curve has a bump; the absolute 0.01 dB the round-4 review asked for at step 200 is met by NO fp32 arithmetic, torch's
+included.  The bar therefore is relative (tests/test_hip_trajectory.py asserts it): at every checkpoint, for every engine mode,
+  |loss - loss_f64| and |PSNR - PSNR_f64|  <=  2 x the largest such distance among the deterministic yard-sticks (float32 on
+  the host cores and the ulp-perturbed float64 runs), never less than one float32 ulp of the quantity.
+`verdict()` also lists which runs meet 0.01 dB at the last checkpoint (for the record; the yard-sticks' own figures beside it).
 
 Run on the GPU box: `python tools/trajectory.py [--steps 200] [--size 96] [--out profiles/r05_trajectory.txt]`.
 oracle/ is used here as the yard-stick (a tool and a test, never the product path)."""
@@ -91,15 +99,21 @@ def run_engine(mode, state, x, t, xh, th, steps, checkpoints, device="cuda"):
     return [float(v) for v in torch.stack(losses).double().cpu()], ck
 
 
-def run_torch(dtype_name, state, x, t, xh, th, steps, checkpoints, device="cuda"):
-    """the same graph, loss and optimizer in torch (oracle.torch_forward: the restatement the goldens pin to the reference)"""
+def run_torch(dtype_name, state, x, t, xh, th, steps, checkpoints, device="cuda", perturb_seed=None):
+    """the same graph, loss and optimizer in torch (oracle.torch_forward: the restatement the goldens pin to the reference);
+    perturb_seed: every start weight times (1 + d 2^-23), d uniform in {-1, 0, 1} (float64 runs: at most one fp32 ulp each)"""
     import torch
     from oracle import oracle
     dt = {"float64": torch.float64, "float32": torch.float32}[dtype_name]
     if device == "cpu":
         torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     # clone: .to() of a float32 CPU tensor to float32 CPU is the tensor itself, and Adam updates in place
-    st = {k: v.detach().clone().to(device=device, dtype=dt).requires_grad_(True) for k, v in state.items()}
+    st = {k: v.detach().clone().to(dtype=dt) for k, v in state.items()}
+    if perturb_seed is not None:
+        g = torch.Generator().manual_seed(perturb_seed)
+        for k in st:
+            st[k] = st[k] * (1.0 + (torch.randint(-1, 2, st[k].shape, generator=g).to(dt)) * 2.0 ** -23)
+    st = {k: v.to(device).requires_grad_(True) for k, v in st.items()}
     opt = torch.optim.Adam(list(st.values()), lr=LR, betas=BETAS, eps=1e-8)
     xd, td, xhd, thd = (torch.from_numpy(a).to(device=device, dtype=dt) for a in (x, t, xh, th))
     losses, ck = [], {}
@@ -115,18 +129,20 @@ def run_torch(dtype_name, state, x, t, xh, th, steps, checkpoints, device="cuda"
     return [float(v) for v in torch.stack(losses).double().cpu()], ck
 
 
-def run_all(steps=200, size=96, checkpoints=(50, 100, 200), cpu_f32=False, log=print):
-    """-> {leg: (losses, {checkpoint: [psnr tile 0, psnr tile 1]})}; legs: the three engine modes, 'float64', 'float32' (GPU),
-    and 'float32_cpu' when asked for"""
+def run_all(steps=200, size=96, checkpoints=(50, 100, 200), cpu_f32=True, members=3, gpu_f32=True, log=print):
+    """-> {leg: (losses, {checkpoint: [psnr tile 0, psnr tile 1]})}; legs: 'float64', 'float64_ulp<i>' (members), 'float32_cpu',
+    'float32' (GPU, not deterministic), the three engine modes"""
     checkpoints = tuple(c for c in checkpoints if c <= steps)
     state = start_state()
     x, t = denoise_pairs(4, size, 11)
     xh, th = denoise_pairs(2, size, 23)
     out = {}
-    legs = [("float64", lambda: run_torch("float64", state, x, t, xh, th, steps, checkpoints)),
-            ("float32", lambda: run_torch("float32", state, x, t, xh, th, steps, checkpoints))]
+    legs = [("float64", lambda: run_torch("float64", state, x, t, xh, th, steps, checkpoints))]
+    legs += [(f"float64_ulp{i}", (lambda i=i: run_torch("float64", state, x, t, xh, th, steps, checkpoints, perturb_seed=100 + i))) for i in range(members)]
     if cpu_f32:
         legs.append(("float32_cpu", lambda: run_torch("float32", state, x, t, xh, th, steps, checkpoints, device="cpu")))
+    if gpu_f32:
+        legs.append(("float32", lambda: run_torch("float32", state, x, t, xh, th, steps, checkpoints)))
     legs += [(m, (lambda m=m: run_engine(m, state, x, t, xh, th, steps, checkpoints))) for m in ENGINE_MODES]
     import torch
     start = {k: v.clone() for k, v in state.items()}
@@ -141,11 +157,18 @@ def run_all(steps=200, size=96, checkpoints=(50, 100, 200), cpu_f32=False, log=p
 F32_ULP = 2.0 ** -23
 
 
+def yard_sticks(res):
+    """the deterministic yard-sticks of the bar: float32 on the host cores and the ulp-perturbed float64 runs (the GPU float32
+    run only when neither exists)"""
+    y = [k for k in res if k == "float32_cpu" or k.startswith("float64_ulp")]
+    return y or [k for k in res if k == "float32"]
+
+
 def verdict(res, checkpoints):
     """rows (leg, checkpoint, |dloss|, |dpsnr| worst tile, yard |dloss|, yard |dpsnr|, ok) for the engine modes; the yard-stick is
-    the larger float32 distance to float64, floored at one float32 ulp of the quantity"""
+    the largest distance to float64 among yard_sticks(res), floored at one float32 ulp of the quantity"""
     ref_l, ref_p = res["float64"]
-    yards = [k for k in ("float32", "float32_cpu") if k in res]
+    yards = yard_sticks(res)
     rows = []
     for leg in ENGINE_MODES:
         if leg not in res:
@@ -155,7 +178,7 @@ def verdict(res, checkpoints):
             dp = max(abs(a - b) for a, b in zip(res[leg][1][c], ref_p[c]))
             yl = max(max(abs(res[y][0][c - 1] - ref_l[c - 1]) for y in yards), F32_ULP * abs(ref_l[c - 1]))
             yp = max(max(max(abs(a - b) for a, b in zip(res[y][1][c], ref_p[c])) for y in yards), F32_ULP * max(ref_p[c]))
-            ok = dl <= 2 * yl and dp <= 2 * yp and (c != checkpoints[-1] or dp <= 0.01)
+            ok = dl <= 2 * yl and dp <= 2 * yp
             rows.append((leg, c, dl, dp, yl, yp, ok))
     return rows
 
@@ -187,7 +210,13 @@ def report(res, checkpoints, steps, size):
             lines.append(f"  {leg:<20s}                " + "".join(
                 f"{max(abs(a - b) for a, b in zip(res[leg][1][c], ref_p[c])):14.3e}" for c in checkpoints))
     rows = verdict(res, checkpoints)
-    lines += ["", "bar: |dloss| <= 2 x float32's, |dPSNR| <= 2 x float32's at every checkpoint; |dPSNR| <= 0.01 dB at the last",
+    last = checkpoints[-1]
+    lines += ["", f"who is within 0.01 dB of float64 at step {last} (worst tile)?"]
+    for leg in res:
+        if leg != "float64":
+            d = max(abs(a - b) for a, b in zip(res[leg][1][last], ref_p[last]))
+            lines.append(f"  {leg:<20s}{d:10.4f} dB   {'yes' if d <= 0.01 else 'no'}")
+    lines += ["", "bar: |dloss| and |dPSNR| <= 2 x the largest distance among the yard-sticks (" + ", ".join(yard_sticks(res)) + ") at every checkpoint",
               f"  {'mode':<8s}{'step':>6s}{'|dloss|':>12s}{'2 x yard':>12s}{'|dPSNR|':>12s}{'2 x yard':>12s}   ok"]
     for leg, c, dl, dp, yl, yp, ok in rows:
         lines.append(f"  {leg:<8s}{c:6d}{dl:12.3e}{2 * yl:12.3e}{dp:12.3e}{2 * yp:12.3e}   {'yes' if ok else 'NO'}")
@@ -201,11 +230,12 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--size", type=int, default=96)
     ap.add_argument("--checkpoints", default="50,100,200")
-    ap.add_argument("--cpu-f32", action="store_true", help="also run torch float32 on the host cores (oneDNN) as a second yard-stick")
+    ap.add_argument("--no-cpu-f32", action="store_true", help="skip torch float32 on the host cores (oneDNN)")
+    ap.add_argument("--members", type=int, default=4, help="float64 runs from starts perturbed by <= 1 fp32 ulp per weight")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     cps = tuple(int(c) for c in a.checkpoints.split(","))
-    res, cps = run_all(a.steps, a.size, cps, a.cpu_f32)
+    res, cps = run_all(a.steps, a.size, cps, not a.no_cpu_f32, a.members)
     text, rows = report(res, cps, a.steps, a.size)
     print(text)
     if a.out:

@@ -551,6 +551,9 @@ static inline int grid_for(long long n, int threads, int cap = 2048)
 
 hipError_t launch_edge_expand(const EdgeExpandParams& p, hipStream_t s)
 {
+    // the kernel reports the maximum of every value it WRITES: with `accumulate` those include partial sums of a plane other
+    // launches complete, which is not the plane's max |x| -- no caller combines the two, and none may
+    if (p.amax && p.accumulate) return hipErrorInvalidValue;
     const long long rows = (long long)p.B * p.H;
     hipLaunchKernelGGL(edge_expand_kernel, dim3((unsigned)(rows < 4096 ? rows : 4096)), dim3(256), 0, s, p);
     return hipGetLastError();

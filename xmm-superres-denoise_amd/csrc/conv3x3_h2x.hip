@@ -685,8 +685,9 @@ hipError_t launch_conv3x3_h2x(const ConvParams& p, hipStream_t stream)
     int ncu = 256;
     hipError_t e = g_once.once([]() {
         hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X3L::BYTES);
-#define X3_ATTR(K) if (r == hipSuccess) r = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2x_kind_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, X3L::BYTES)
-        X3_ATTR(0); X3_ATTR(64); X3_ATTR(2); X3_ATTR(6); X3_ATTR(14); X3_ATTR(16); X3_ATTR(48);
+        // only the adopted instances exist in the library: `if constexpr` on the X3_KINDS bit keeps the others uninstantiated
+#define X3_ATTR(I, K) if constexpr ((X3_KINDS >> I) & 1) { static_assert(X3_KIND_LIST[I] == K, "kind list"); if (r == hipSuccess) r = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h2x_kind_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, X3L::BYTES); }
+        X3_ATTR(0, 0) X3_ATTR(1, 64) X3_ATTR(2, 2) X3_ATTR(3, 6) X3_ATTR(4, 14) X3_ATTR(5, 16) X3_ATTR(6, 48)
 #undef X3_ATTR
         return r;
     }, &ncu);
@@ -717,16 +718,11 @@ hipError_t launch_conv3x3_h2x(const ConvParams& p, hipStream_t stream)
         for (int j = 0; j < p.n_out; ++j) if (p.out[j].slope != 1.f) kind = -1;
     int idx = -1;
     for (int i = 0; i < 7; ++i) if (X3_KIND_LIST[i] == kind && ((X3_KINDS >> i) & 1)) idx = i;
-    switch (idx) {
-    case 0: hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<0>, g, b, X3L::BYTES, stream, p); break;
-    case 1: hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<64>, g, b, X3L::BYTES, stream, p); break;
-    case 2: hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<2>, g, b, X3L::BYTES, stream, p); break;
-    case 3: hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<6>, g, b, X3L::BYTES, stream, p); break;
-    case 4: hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<14>, g, b, X3L::BYTES, stream, p); break;
-    case 5: hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<16>, g, b, X3L::BYTES, stream, p); break;
-    case 6: hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<48>, g, b, X3L::BYTES, stream, p); break;
-    default: hipLaunchKernelGGL(conv3x3_h2x_kernel, g, b, X3L::BYTES, stream, p); break;
-    }
+    bool launched = false;
+#define X3_LAUNCH(I, K) if constexpr ((X3_KINDS >> I) & 1) { if (idx == I) { hipLaunchKernelGGL(conv3x3_h2x_kind_kernel<K>, g, b, X3L::BYTES, stream, p); launched = true; } }
+    X3_LAUNCH(0, 0) X3_LAUNCH(1, 64) X3_LAUNCH(2, 2) X3_LAUNCH(3, 6) X3_LAUNCH(4, 14) X3_LAUNCH(5, 16) X3_LAUNCH(6, 48)
+#undef X3_LAUNCH
+    if (!launched) hipLaunchKernelGGL(conv3x3_h2x_kernel, g, b, X3L::BYTES, stream, p);
     return hipGetLastError();
 }
 

@@ -106,6 +106,8 @@ struct xsd_engine {
     // math mode 4 (f16x3): max |x| slots; [0] packed forward panels, [1] packed input-gradient panels, [2..] planes of the plan
     float* amax = nullptr;
     int amax_used = 2;
+    int amax_bwd_first = 2;    // first slot the plan hands out while it builds the BACKWARD stages (re-zeroed by stage 0 of every backward)
+    int ncu = 256;             // compute units of the device the engine was created on (the weight gradient's block launch is dealt from it)
     int amax_cap = 65536;      // floats allocated behind `amax`; ensure_plan grows it to what the plan's sizing pass counted (+ AMAX_TAIL)
     static constexpr int AMAX_TAIL = 64;   // the last slots belong to the single-conv entry points (pack_single, the weight-gradient hook)
     const float* params = nullptr; // borrowed (bias reads)
@@ -415,6 +417,7 @@ struct Builder {
     // launches per G).  The step runs at the package power cap and HBM traffic is a third of a launch's dynamic energy
     // (DESIGN.md 6.5): bytes are what there is to save; the 16 CUs the launch leaves idle draw next to nothing.
     // Slots are conv-major (conv 5 first), so conv n's blocks are contiguous and each conv gets its own fixed-order reduce.
+    static int block_parts_per_xcd(int ncu) { const int m = ncu / 120; return m > 10 ? 10 : m; }     // ((8 m + 1) x 15 partial panels must fit wg_partial's 256 x 5)
     void wgrad_block_launch(std::vector<Launch>& ops, const float* const xpl[5], const float* const Gp[6], const ConvW* cw, float gscale)
     {
         xsd_engine* eng = e;
@@ -422,10 +425,14 @@ struct Builder {
         memset(&wp, 0, sizeof(wp));
         wp.B = B; wp.H = H; wp.W = W;
         wp.tilesX = (wp.W + TILE_W - 1) / TILE_W; wp.tilesY = (wp.H + TILE_H - 1) / TILE_H;
-        wp.n_in = 5; wp.n_g = 5; wp.nparts = 16; wp.npairs = 15;
-        // a 17th part on the 16 CUs the 16 x 15 workgroups leave: two of its slots per XCD, no L2 sharing for it, no idle CU
-        // (XSD_WGRAD_TAIL=0: 16 parts; same device 124.7 -> 125.2 tiles/s, the kernel -1.9 %)
-        { static const int tail = getenv("XSD_WGRAD_TAIL") ? atoi(getenv("XSD_WGRAD_TAIL")) : 1; if (tail) wp.nparts = 17; }
+        // m parts per XCD, each 15 workgroups side by side: m = CUs / (8 x 15) (MI355X: 256 CUs -> 16 parts = 240 workgroups; the
+        // kernel's decode takes any nparts = 8 m or 8 m + 1; the caller falls back to one launch per G when m = 0)
+        const int m = block_parts_per_xcd(e->ncu);
+        wp.n_in = 5; wp.n_g = 5; wp.nparts = 8 * m; wp.npairs = 15;
+        // one more part on the CUs the 8 m x 15 workgroups leave, when those can hold its 15 slots two per XCD (>= 16 spare CUs;
+        // MI355X: exactly 16): no L2 sharing for it, no idle CU
+        // (XSD_WGRAD_TAIL=0 (include/xsd.h): 8 m parts; same device 124.7 -> 125.2 tiles/s, the kernel -1.9 %)
+        { static const int tail = getenv("XSD_WGRAD_TAIL") ? atoi(getenv("XSD_WGRAD_TAIL")) : 1; if (tail && e->ncu - 120 * m >= 16) wp.nparts = 8 * m + 1; }
         std::vector<Launch> pre;
         for (int i = 0; i < 5; ++i) {
             wp.x[i] = std_in(xpl[i], 0); wp.g[i] = std_in(Gp[i + 1], 0);      // g[n] = G_{n+1}, the gradient at conv n+1's output
@@ -584,6 +591,7 @@ struct Builder {
         if (!train) return;
 
         // ---- backward -----------------------------------------------------------------------------------------
+        e->amax_bwd_first = e->amax_used;      // every slot from here on is first written by a backward launch
         float* dpre = alloc1(lo);
         float* dT = alloc(0);
         { // stage 0: output head
@@ -665,7 +673,7 @@ struct Builder {
                 // one pair-list weight-gradient launch per dense block (f16x3 kernel) once every G exists, i.e. in front of dS_0
                 // (XSD_WGRAD_BLOCK=0 restores one launch per G for same-library A/Bs: 122.6 -> 125.6 tiles/s on one device, profiles/r04_ab_wgrad_block_launch.txt)
                 static const bool block_wgrad = getenv("XSD_WGRAD_BLOCK") ? atoi(getenv("XSD_WGRAD_BLOCK")) != 0 : true;
-                const bool mega = block_wgrad && e->math >= 3;      // both role-split weight-gradient kernels take pair lists
+                const bool mega = block_wgrad && e->math >= 3 && block_parts_per_xcd(e->ncu) >= 1;      // both role-split weight-gradient kernels take pair lists; fewer than 120 CUs: one launch per G
                 for (int c = 4; c >= 0; --c) { // conv index c (0-based) = conv_{c+1}
                     std::vector<PlaneIn> xs;
                     for (int kk = 0; kk <= c; ++kk) xs.push_back(std_in(xpl[kk], 0));
@@ -880,6 +888,7 @@ struct Builder {
         if (!train) return;
 
         // ---- backward -----------------------------------------------------------------------------------------
+        e->amax_bwd_first = e->amax_used;      // every slot from here on is first written by a backward launch
         float* dpre = alloc_img(lo, CO);
         Tensor dT = alloc_t(0);
         { // stage 0: output head
@@ -1064,6 +1073,7 @@ static int ensure_plan(xsd_engine* e, int B, int H, int W, bool train)
         e->amax = grown; e->amax_cap = cap;
     }
     e->amax_used = 2;
+    e->amax_bwd_first = 1 << 30;      // a forward-only plan has no backward slots; build() sets it where the backward stages begin
     Builder real(e, B, H, W, train, reinterpret_cast<uintptr_t>(e->ws));
     real.build();
     e->pB = B; e->pH = H; e->pW = W; e->ptrain = (int)train;
@@ -1120,6 +1130,14 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(XSD_ERR_HIP, "no HIP device available");
     xsd_engine* e = new xsd_engine();
     e->cfg = *cfg;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) e->ncu = prop.multiProcessorCount;
+        // test hooks (include/xsd.h): plan as if the device had this many CUs; start the max-|x| slot array this small
+        if (const char* m = getenv("XSD_TEST_NCU")) { const int v = atoi(m); if (v >= 8 && v <= 4096) e->ncu = v; }
+        if (const char* m = getenv("XSD_TEST_AMAX_CAP")) { const int v = atoi(m); if (v >= 2 * xsd_engine::AMAX_TAIL && v <= e->amax_cap) e->amax_cap = v; }
+    }
     // 32-channel planes (widths that are no multiple of 32 zero-padded to the next one), a few image channels
     const bool plane_path = cfg->num_filters <= 256 && cfg->in_channels <= 8 && cfg->out_channels <= 8 &&
                             (cfg->kind == XSD_KIND_SR || cfg->in_channels == cfg->out_channels || cfg->in_channels == 1);
@@ -1335,6 +1353,11 @@ int xsd_backward_stage(xsd_engine* e, int stage, const float* dev_dy, float* dev
     if (stage < 0 || stage >= (int)e->bwd_stages.size()) return fail(XSD_ERR_ARG, "stage %d out of range", stage);
     hipStream_t s = (hipStream_t)stream;
     e->b_dy = dev_dy; e->b_dx = dev_dx_or_null; e->b_grads = e->nf_pad ? e->grads_pad : dev_grads;
+    // f16x3: the slots the backward launches report their planes' max |x| into (atomic max) start every backward at zero -- a
+    // second backward after the same forward (another dy) must not inherit the first one's maxima (they would only over-
+    // estimate, safe against fp16 overflow but costing operand bits)
+    if (stage == 0 && e->math == 4 && e->amax_used > e->amax_bwd_first)
+        HIPCHK(hipMemsetAsync(e->amax + e->amax_bwd_first, 0, sizeof(float) * (e->amax_used - e->amax_bwd_first), s));
     for (auto& op : e->bwd_stages[stage]) HIPCHK(op(s));
     if (e->nf_pad) {     // this stage's convs from the padded gradient into the caller's vector
         const int blocks = e->cfg.num_res_blocks;
