@@ -119,6 +119,9 @@ def test_bench_one_rank_over_rccl_with_the_reduce_path_forced():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["dist_backend"] == "nccl" and d["config"]["parallelism"] == "dp1"
     assert d["replicas_identical"] is True and d["value"] > 0
+    # the exchange wait on RCCL's stream, measured by the event pair around the wait loop (one rank: microseconds, never negative)
+    assert d["per_rank"]["comm_ms_exposed"][0] is not None and 0 <= d["per_rank"]["comm_ms_exposed"][0] < 5.0, d["per_rank"]
+    assert len(d["per_rank"]["ms_per_step"]) == 1
 
 
 def test_bench_line_reports_package_power_and_clock():
@@ -137,8 +140,14 @@ def test_bench_line_reports_package_power_and_clock():
     pw = d.get("power")
     if pw is None:
         pytest.skip("no readable amdgpu hwmon files on this box")
-    assert pw["cap_w"] and 0.5 < pw["frac_of_cap"] <= 1.05, pw      # measured: 0.93 (short run, ramp included) ... 0.999
+    assert pw["cap_w"] and 0.9 < pw["frac_of_cap"] <= 1.05, pw      # sampled from the post-warm-up synchronize to the closing one: no idle samples
     assert 500 <= pw["sclk_mhz"] <= 2600 and pw["samples"] >= 3, pw
+    # the roof the power cap leaves, measured in the bench process: the conv's bare MFMA stream sustains 0.5 - 0.8 of the nominal peak
+    r = d["roofline"]
+    assert 0.4 * r["peak"] < r["sustained_peak"] < 0.95 * r["peak"], r
+    assert abs(r["frac_of_sustained"] - r["achieved"] / r["sustained_peak"]) < 1e-9 and r["frac"] < r["frac_of_sustained"] < 1.0, r
+    assert abs(d["psnr_delta_db"]) < 0.01 and len(d["psnr"]["delta_db_per_tile"]) == 2
+    assert d["comm_ms_exposed"] == 0.0 and "per_rank" not in d        # one process, no process group: no exchange
 
 
 def test_train_driver_one_rank_over_rccl(tmp_path):
@@ -165,7 +174,13 @@ def test_bench_n_ranks_gloo_on_one_gpu(world):
     The JSON line carries the whole-job value and the DDP invariant (bit-identical replicas after the timed steps).
     (Four ranks: gloo's device-tensor all-reduce stalls behind device work when three or more processes share one GPU
     (tools/gloo_cuda_probe.py, profiles/r04_gloo_cuda_probe.txt); under gloo the gradient slices are reduced through a pinned
-    host buffer -- copied on a side stream behind an event, the host never blocks the enqueue of later stages: parallel.py.)"""
+    host buffer -- copied on a side stream behind an event, the host never blocks the enqueue of later stages: parallel.py.)
+    Four ranks is as far as one box goes: the pool allows six processes with the card open, and this test process and the
+    launcher are two of them (round 5 tried five ranks: "graft-proclimit: killed the run: 7 processes had the GPU open (limit
+    6)"; the round-4 review's 8-rank rehearsal on the one GPU cannot run here).  The 8-rank form of the trainer's logic runs on
+    the CPU: tests/test_parallel_gloo.py::test_dp8_matches_single_process.
+    The line explains a multi-GPU result by itself: `per_rank` carries every rank's own step time, device clock, watts and the
+    time its compute stream waited for the gradient exchange (`comm_ms_exposed`), beside the max-over-ranks `ms_per_step`."""
     import json
     root = os.path.dirname(HERE)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -174,13 +189,19 @@ def test_bench_n_ranks_gloo_on_one_gpu(world):
     if torch.cuda.device_count() < world:
         env["XSD_DIST_BACKEND"] = "gloo"
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch", "2",
-                        "--no-extra", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+                        "--no-extra", "--no-cpu-baseline", "--sustained-seconds", "0.2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = p.stdout.decode(errors="replace")
     assert p.returncode == 0, out[-3000:]
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out[-3000:]          # rank 0 prints exactly one JSON line
     d = json.loads(lines[0])
     assert d["n_gpus"] == world and d["value"] > 0 and d["scaling"] == "weak" and d["steps"] == 2
+    pr = d["per_rank"]
+    assert all(len(pr[k]) == world for k in ("ms_per_step", "sclk_mhz", "avg_w", "comm_ms_exposed", "sustained_mfma_tflops", "pci")), pr
+    assert all(0 < v <= d["ms_per_step"] * 1.001 for v in pr["ms_per_step"]), (pr, d["ms_per_step"])     # the line's figure is the MAX over ranks
+    assert all(v is not None and 0 <= v < d["ms_per_step"] for v in pr["comm_ms_exposed"]), pr
+    assert d["comm_ms_exposed"] == pr["comm_ms_exposed"][0]
+    assert "psnr_delta_db" in d and abs(d["psnr_delta_db"]) < 0.01
     assert d["config"]["per_gpu_batch"] == 2 and d["config"]["global_batch"] == 2 * world and d["config"]["parallelism"] == f"dp{world}"
     assert d["replicas_identical"] is True
     assert abs(d["value"] - 2 * world * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]      # value = all ranks' tiles / max-over-ranks time

@@ -15,12 +15,12 @@ pytestmark = pytest.mark.gpu
 
 def test_training_trajectory_every_math_mode_vs_float64():
     """DN 32 x 4, fixed batch of 4 tiles of 64 x 64, seeded reference init, 200 steps of L1 + Adam(1e-4).  The optimisation is
-    chaotic at the 0.02 - 0.35 dB level for EVERY fp32 arithmetic, torch's included (tools/trajectory.py, profiles/
-    r05_trajectory.txt), so the bar is relative: at steps 50 / 100 / 200 the engine's loss and the PSNR of two held-out tiles
-    sit within 2 x the largest distance to the float64 run among the deterministic yard-sticks -- torch float32 on the host cores
-    (oneDNN) and three float64 runs whose start weights are moved by at most one fp32 ulp -- for f16x3 (the headline mode), bf16x6
-    and fp32 alike.  Everything in the bar is deterministic (the engine is bitwise reproducible; MIOpen's float32 is not, and is
-    only printed)."""
+    chaotic for EVERY arithmetic: float64 from start weights moved by one fp32 ulp ends 0.01 - 0.5 dB from float64, torch's two
+    float32 paths 0.03 - 0.3 dB, and so do the engine's three modes, on every data set scanned (tools/trajectory.py,
+    tools/trajectory_scan.py, profiles/r05_trajectory*.txt).  Held here, for f16x3 (the headline mode), bf16x6 and fp32 alike:
+    at step 50 -- before the divergence has grown -- the PSNR of two held-out tiles within 0.01 dB of the float64 run's; at steps
+    50 / 100 / 200 loss and PSNR within 2 x the largest distance to the float64 run among the yard-sticks (torch float32 on the
+    host cores and on the GPU, three float64 runs from ulp-perturbed starts)."""
     import trajectory as tj
     assert torch.cuda.is_available()
     res, cps = tj.run_all(steps=200, size=64, checkpoints=(50, 100, 200), cpu_f32=True, members=3, gpu_f32=True, log=lambda s: print(s, flush=True))
@@ -35,3 +35,6 @@ def test_training_trajectory_every_math_mode_vs_float64():
     assert {r[0] for r in rows} == set(tj.ENGINE_MODES)
     bad = [r for r in rows if not r[-1]]
     assert not bad, bad
+    for leg in tj.ENGINE_MODES:      # the absolute figure where it is meaningful
+        d = max(abs(a - b) for a, b in zip(res[leg][1][50], res["float64"][1][50]))
+        assert d <= tj.ABS_BAR_DB, (leg, d)

@@ -70,18 +70,18 @@ def _make(kind, blocks, seed):
     return m
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, nglobal=4):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from xmm_superres_denoise.parallel import DataParallelTrainer
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     blocks = 1
     # rank 1 starts from different weights on purpose: the constructor's broadcast must fix that
     m = _make("dn", blocks, 300 + (7 if rank == 1 else 0))
     tr = DataParallelTrainer(m, lr=1e-4, engine=OracleEngine("dn", blocks))
-    X = torch.from_numpy(gc.make_input((4, 1, 12, 20), 301))
-    T = torch.from_numpy(gc.make_input((4, 1, 12, 20), 302))
+    X = torch.from_numpy(gc.make_input((nglobal, 1, 12, 20), 301))
+    T = torch.from_numpy(gc.make_input((nglobal, 1, 12, 20), 302))
     x, t = tr.shard(X), tr.shard(T)
     losses = []
     for _ in range(2):
@@ -114,6 +114,30 @@ def test_dp2_matches_single_process():
     assert np.abs(p0 - tr.flat.numpy()).max() < 2e-6
     start = np.concatenate([v.ravel() for v in gc.make_state("dn", 32, 1, 300).values()])
     assert np.abs(p0 - start).max() > 1e-4  # it actually trained
+
+
+def test_dp8_matches_single_process():
+    """BASELINE configs[4]'s rank count: eight ranks (one tile each of a global batch of eight), the staged all-reduce of every
+    gradient slice, Adam with grad_scale = 1/8 -- against one process on the full batch.  (On the GPU box the bench rehearses
+    at most four ranks on the one card: tests/test_hip_parallel.py.)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(8, port, ret, 8), nprocs=8, join=True)
+    from xmm_superres_denoise.parallel import DataParallelTrainer
+    m = _make("dn", 1, 300)
+    tr = DataParallelTrainer(m, lr=1e-4, engine=OracleEngine("dn", 1))
+    X = torch.from_numpy(gc.make_input((8, 1, 12, 20), 301))
+    T = torch.from_numpy(gc.make_input((8, 1, 12, 20), 302))
+    losses = [float(tr.train_step(X, T)) for _ in range(2)]
+    for r in range(1, 8):
+        assert np.array_equal(ret[0][0], ret[r][0]), f"replica {r} diverged"
+        assert np.allclose(ret[r][1], losses, atol=1e-6)
+    assert np.abs(ret[0][0] - tr.flat.numpy()).max() < 2e-6
+    start = np.concatenate([v.ravel() for v in gc.make_state("dn", 32, 1, 300).values()])
+    assert np.abs(ret[0][0] - start).max() > 1e-4
 
 
 def _metric_worker(rank, world, port, ret):

@@ -23,10 +23,15 @@ What the first runs showed (profiles/r05_trajectory.txt): this optimisation is c
 fp32-class run -- torch's own two float32 paths, the exact-fp32 MFMA mode, the exact bf16x6 split, f16x3 -- and every
 ulp-perturbed float64 run ends 0.02 - 0.3 dB from the float64 run at step 200 and up to 0.35 dB around step 100, where the
 loss curve has a bump; the absolute 0.01 dB the round-4 review asked for at step 200 is met by NO fp32 arithmetic, torch's
-included.  The bar therefore is relative (tests/test_hip_trajectory.py asserts it): at every checkpoint, for every engine mode,
-  |loss - loss_f64| and |PSNR - PSNR_f64|  <=  2 x the largest such distance among the deterministic yard-sticks (float32 on
-  the host cores and the ulp-perturbed float64 runs), never less than one float32 ulp of the quantity.
-`verdict()` also lists which runs meet 0.01 dB at the last checkpoint (for the record; the yard-sticks' own figures beside it).
+included -- float64 itself misses it by 0.01 - 0.49 dB when its start weights move by one fp32 ulp.  tools/trajectory_scan.py
+(profiles/r05_trajectory_scan.txt) ran 24 other data sets (tile 64 - 128, batch 4 / 16, two seeds, two noise levels): the three
+engine modes stay within 5e-3 dB of each other up to step 50 on every one and are 0.02 - 1.6 dB apart by step 200 on every one.
+The chaos belongs to the optimisation (random init, Adam at 1e-4 on an L1 loss), not to any arithmetic or data choice.
+The bar (tests/test_hip_trajectory.py asserts it), for every engine mode:
+  * step 50 (before the divergence has grown): |PSNR - PSNR_f64| <= 0.01 dB, the review's figure, where it means something;
+  * every checkpoint: |loss - loss_f64| and |PSNR - PSNR_f64| <= 2 x the largest such distance among the yard-sticks (torch
+    float32 on the host cores and on the GPU, the ulp-perturbed float64 runs).
+`report()` also lists which runs meet 0.01 dB at the last checkpoint (for the record; the yard-sticks' own figures beside it).
 
 Run on the GPU box: `python tools/trajectory.py [--steps 200] [--size 96] [--out profiles/r05_trajectory.txt]`.
 oracle/ is used here as the yard-stick (a tool and a test, never the product path)."""
@@ -157,33 +162,22 @@ def run_all(steps=200, size=96, checkpoints=(50, 100, 200), cpu_f32=True, member
 F32_ULP = 2.0 ** -23
 
 
+PRE_CHAOS_STEP = 50      # up to here three fp32-class arithmetics stay within ~5e-3 dB of each other on every data set scanned
+ABS_BAR_DB = 0.01        # the round-4 review's absolute figure: meaningful (and asserted) at the pre-chaotic checkpoint
+
+
 def yard_sticks(res):
-    """the deterministic yard-sticks of the bar: float32 on the host cores and the ulp-perturbed float64 runs (the GPU float32
-    run only when neither exists)"""
-    y = [k for k in res if k == "float32_cpu" or k.startswith("float64_ulp")]
-    return y or [k for k in res if k == "float32"]
+    """every run that is NOT an engine mode and not the float64 reference: torch float32 (host cores, GPU) and the ulp-perturbed
+    float64 runs"""
+    return [k for k in res if k not in ENGINE_MODES and k != "float64"]
 
 
 def verdict(res, checkpoints):
-    """rows (leg, checkpoint, |dloss|, |dpsnr| worst tile, yard |dloss|, yard |dpsnr|, ok) for the engine modes; the yard-stick is
-    the largest distance to float64 among yard_sticks(res), floored at one float32 ulp of the quantity"""
+    """rows (leg, checkpoint, |dloss|, |dpsnr| worst tile, yard |dloss|, yard |dpsnr|, ok) for the engine modes.  Yard-stick = the
+    largest distance to float64 among yard_sticks(res), floored at 2e-5 (loss) / one float32 ulp of the PSNR.  ok = both distances
+    within 2 x the yard-stick's, and at checkpoints <= PRE_CHAOS_STEP also |dPSNR| <= ABS_BAR_DB."""
     ref_l, ref_p = res["float64"]
-    yards = yard_sticks(res)
-    rows = []
-    for leg in ENGINE_MODES:
-        if leg not in res:
-            continue
-        for c in checkpoints:
-            dl = abs(res[leg][0][c - 1] - ref_l[c - 1])
-            dp = max(abs(a - b) for a, b in zip(res[leg][1][c], ref_p[c]))
-            yl = max(max(abs(res[y][0][c - 1] - ref_l[c - 1]) for y in yards), F32_ULP * abs(ref_l[c - 1]))
-            yp = max(max(max(abs(a - b) for a, b in zip(res[y][1][c], ref_p[c])) for y in yards), F32_ULP * max(ref_p[c]))
-            ok = dl <= 2 * yl and dp <= 2 * yp
-            rows.append((leg, c, dl, dp, yl, yp, ok))
-    return rows
-
-
-def report(res, checkpoints, steps, size):
+    yards = yard_sticks(res)def report(res, checkpoints, steps, size):
     ref_l, ref_p = res["float64"]
     lines = [f"DN 32 filters x 4 blocks, 4 tiles of {size}x{size}, mean-L1 + Adam(lr 1e-4, betas (0.9, 0.999)), {steps} steps from the "
              "reference-default init (seed 0); 2 held-out tiles",
@@ -216,7 +210,7 @@ def report(res, checkpoints, steps, size):
         if leg != "float64":
             d = max(abs(a - b) for a, b in zip(res[leg][1][last], ref_p[last]))
             lines.append(f"  {leg:<20s}{d:10.4f} dB   {'yes' if d <= 0.01 else 'no'}")
-    lines += ["", "bar: |dloss| and |dPSNR| <= 2 x the largest distance among the yard-sticks (" + ", ".join(yard_sticks(res)) + ") at every checkpoint",
+    lines += ["", "bar: |dloss| and |dPSNR| <= 2 x the largest distance among the yard-sticks (" + ", ".join(yard_sticks(res)) + f") at every checkpoint; |dPSNR| <= {ABS_BAR_DB} dB up to step {PRE_CHAOS_STEP}",
               f"  {'mode':<8s}{'step':>6s}{'|dloss|':>12s}{'2 x yard':>12s}{'|dPSNR|':>12s}{'2 x yard':>12s}   ok"]
     for leg, c, dl, dp, yl, yp, ok in rows:
         lines.append(f"  {leg:<8s}{c:6d}{dl:12.3e}{2 * yl:12.3e}{dp:12.3e}{2 * yp:12.3e}   {'yes' if ok else 'NO'}")

@@ -31,6 +31,9 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef V3_PAIR
+#define V3_PAIR 1      // MFMA waves own (pixel half, row pair) instead of a tile row (round 5; -DV3_PAIR=0: the round-4 walk, for A/Bs)
+#endif
 constexpr int V3_TH = 4;                                              // tile rows = MFMA waves
 constexpr int V3_LT = 256;                                            // staging threads (waves 0..3)
 constexpr int V3_THREADS = V3_LT + 64 * V3_TH;                        // 512
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
         // tiles past the end were staged as zeros (empty descriptors): bsum took 0 from them; tile 0 and 1 were counted once each
     } else {
         // ============================== MFMA waves ==============================
-        const int wv = wid - 4;        // tile row
+        const int wv = wid - 4;
 #pragma unroll
         for (int k = 0; k < 9; ++k)
 #pragma unroll
@@ -273,6 +276,55 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
         const int lane_off = (8 * h + (i16 >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (i16 & 3) * 8;
         lds_barrier();                                                                     // (P)
         V3_TICK(1);
+#if V3_PAIR
+        // Round 5: a wave owns a PIXEL HALF of a ROW PAIR (mf = wv & 1: pixels 16 mf .. 16 mf + 15 = the K of a 32x32x16 MFMA; rows
+        // 2 rp, 2 rp + 1, rp = wv >> 1) instead of a whole tile row.  The nine accumulators are sums over pixels, so they serve both
+        // rows, and the fragment of halo row h at column offset dx is the dy = h operand of the upper row AND the dy = h - 1
+        // operand of the lower one: 12 (dx, h) steps fetch 36 X fragments + 6 G fragments per wave and tile instead of 54 + 6
+        // (LDS fragment reads per tile and CU: 480 -> 336 ds_read_b64_tr_b16, -30 %), for the same 108 MFMAs.  The images, the
+        // staging waves and the final reduction (four partial sums per tap) are unchanged.
+        const int mf = wv & 1, rp = wv >> 1;
+#pragma unroll 1
+        for (int k = 0; k < my_tiles; ++k) {
+            const char* xbase = smem + (k & 1) * V3_BUF + (2 * rp) * (HALO_W * 64) + 16 * mf * 64 + lane_off;   // + term image + (h * 34 + dx) * 64
+            const char* gbase = smem + (k & 1) * V3_BUF + V3_G_OFF + (2 * rp) * (TILE_W * 64) + 16 * mf * 64 + lane_off;   // + term image + q * 32 * 64
+            bf16x8 g[2][3], x[2][3];
+            auto load_g = [&](int q, bf16x8 (&d)[3]) {
+#pragma unroll
+                for (int term = 0; term < 3; ++term) d[term] = v3_tr_frag(gbase, term * V3_GT + q * (TILE_W * 64));
+            };
+            auto load_x = [&](int st, bf16x8 (&d)[3]) {      // step st = 4 dx + h
+                const int dx = st >> 2, hr = st & 3;
+#pragma unroll
+                for (int term = 0; term < 3; ++term) d[term] = v3_tr_frag(xbase, term * V3_XT + (hr * HALO_W + dx) * 64);
+            };
+            auto mac6 = [&](f32x16& a, const bf16x8 (&xx)[3], const bf16x8 (&gg)[3]) {
+                // Running accumulators take every product: 12 roundings per tile row and tap, against 32 for an fp32 fma chain
+                // over the same 32 pixels (single-layer error vs float64: tools/dbg_layer.py).
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xx[2], gg[0], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xx[0], gg[2], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xx[1], gg[1], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xx[1], gg[0], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xx[0], gg[1], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xx[0], gg[0], a, 0, 0, 0);
+            };
+            load_g(0, g[0]);
+            load_g(1, g[1]);
+            load_x(0, x[0]);
+#pragma unroll
+            for (int st = 0; st < 12; ++st) {
+                const int dx = st >> 2, hr = st & 3;
+                if (st + 1 < 12) load_x(st + 1, x[(st + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);   // the requests go out BEFORE this step's MFMAs: 192 - 384 cycles of cover
+                if (hr <= 2) mac6(acc[3 * hr + dx], x[st & 1], g[0]);            // upper row: tap (dy = hr, dx)
+                if (hr >= 1) mac6(acc[3 * (hr - 1) + dx], x[st & 1], g[1]);      // lower row: tap (dy = hr - 1, dx)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            V3_TICK(0);
+            lds_barrier();
+            V3_TICK(1);
+        }
+#else
 #pragma unroll 1
         for (int k = 0; k < my_tiles; ++k) {
             const char* xbase = smem + (k & 1) * V3_BUF + wv * (HALO_W * 64) + lane_off;   // + term image + ((dy*34 + dx + 16*mf) * 64)
@@ -317,6 +369,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
             lds_barrier();
             V3_TICK(1);
         }
+#endif
 #ifdef XSD_DIAG
         if (stamp && tid == V3_LT) { atomicAdd(&P.dbg[17], st[0]); atomicAdd(&P.dbg[18], st[1]); atomicAdd(&P.dbg[21], (unsigned long long)my_tiles); }
 #endif
