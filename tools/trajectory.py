@@ -177,7 +177,22 @@ def verdict(res, checkpoints):
     largest distance to float64 among yard_sticks(res), floored at 2e-5 (loss) / one float32 ulp of the PSNR.  ok = both distances
     within 2 x the yard-stick's, and at checkpoints <= PRE_CHAOS_STEP also |dPSNR| <= ABS_BAR_DB."""
     ref_l, ref_p = res["float64"]
-    yards = yard_sticks(res)def report(res, checkpoints, steps, size):
+    yards = yard_sticks(res)
+    rows = []
+    for leg in ENGINE_MODES:
+        if leg not in res:
+            continue
+        for c in checkpoints:
+            dl = abs(res[leg][0][c - 1] - ref_l[c - 1])
+            dp = max(abs(a - b) for a, b in zip(res[leg][1][c], ref_p[c]))
+            yl = max(max(abs(res[y][0][c - 1] - ref_l[c - 1]) for y in yards), 1e-5)
+            yp = max(max(max(abs(a - b) for a, b in zip(res[y][1][c], ref_p[c])) for y in yards), F32_ULP * max(ref_p[c]))
+            ok = dl <= 2 * yl and dp <= 2 * yp and (c > PRE_CHAOS_STEP or dp <= ABS_BAR_DB)
+            rows.append((leg, c, dl, dp, yl, yp, ok))
+    return rows
+
+
+def report(res, checkpoints, steps, size):
     ref_l, ref_p = res["float64"]
     lines = [f"DN 32 filters x 4 blocks, 4 tiles of {size}x{size}, mean-L1 + Adam(lr 1e-4, betas (0.9, 0.999)), {steps} steps from the "
              "reference-default init (seed 0); 2 held-out tiles",
