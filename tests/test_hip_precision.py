@@ -372,6 +372,20 @@ def test_sr_backward_every_tensor_vs_float64():
         assert errs[mode]["g"] < 5e-3 and errs[mode]["dx"] < 5e-3, mode
 
 
+def test_sr_backward_every_tensor_at_the_configs3_share_vs_float64():
+    """BASELINE configs[3]'s per-GPU share at full size: SR 2x train, 16 tiles of 512 x 512 -> 1024 x 1024, 4 blocks -- every one of
+    the 130 parameter-gradient tensors and dL/dx of every math mode row-wise against float64 (the float64 pass and the flip-
+    candidate pass run on the GPU, two tiles at a time), with the row-wise bars of the 256 x 256 SR case above (flip noise IS
+    the gradient error of this functional).  4096 tiles over the persistent workgroups and 16 batch slices per plane: what the
+    driver's 4-GPU run executes on every rank (round 4 had properties only at this size)."""
+    errs, frac = _net_errors(512, 4, 7901, with_grad=True, batch=16, flip_aware=True, kind="sr", tight_w=2e-3, strict_w=5e-3, with_torch32=False)
+    _table(f"SR 2x, 16 tiles of 512^2 -> 1024^2 x 4 blocks, seed 7901: errors vs float64 ({100 * frac:.0f}% of output pixels unclamped):", errs)
+    for m in SPLITS:
+        assert errs[m]["y"] <= errs["fp32"]["y"], m
+    for mode in MODES:
+        assert errs[mode]["g"] < 5e-3 and errs[mode]["dx"] < 5e-3 and errs[mode]["y"] < 1e-6, mode
+
+
 def test_sr_full_size_forward_error_vs_float64():
     """BASELINE configs[1] at its tile size: SR 2x forward, 512 x 512 -> 1024 x 1024, 4 blocks, batch 2, against float64."""
     errs, frac = _net_errors(512, 4, 7801, with_grad=False, batch=2, kind="sr")

@@ -1,10 +1,10 @@
 # Round profiles on the GPU box: rocprofv3 kernel stats of the default bench line (f16x3) and of the strict / exact modes, PMC
 # traffic passes (separate --pmc runs, kernel-trace only), SQ counter passes of the f16x3 train step, plain bench lines of every
-# workload.  Everything lands in gpurun_out/prof_<tag>/ named for profiles/.  usage: bash tools/profile_round.sh r04
-R=$GRAFT_REPO_ROOT; TAG=${1:-r04}; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
+# workload.  Everything lands in gpurun_out/prof_<tag>/ named for profiles/.  usage: bash tools/profile_round.sh r05
+R=$GRAFT_REPO_ROOT; TAG=${1:-r05}; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for M in f16x3 bf16x6 fp32; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$M -- python3 $R/bench.py --math $M --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $O/${TAG}_dn_train_b32_${M}_bench_under_rocprof.json 2> $O/stats_$M.err || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$M -- python3 $R/bench.py --math $M --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-sustained --no-psnr > $O/${TAG}_dn_train_b32_${M}_bench_under_rocprof.json 2> $O/stats_$M.err || exit 1
   cp $(ls $O/stats_$M/*/*kernel_stats.csv | head -1) $O/${TAG}_dn_train_b32_${M}_kernel_stats.csv
   echo "stats $M done"
 done
@@ -13,6 +13,9 @@ for M in f16x3 bf16x6; do bash tools/traffic.sh $M 32 $TAG > $O/traffic_$M.log 2
 # SQ counters of the f16x3 kernels over one train step at the bench batch (matrix pipe busy, issue stalls, LDS conflicts)
 PMC_BATCH=32 PMC_WORKLOAD=dn_train bash tools/pmc.sh f16x3 > $O/pmc_f16x3.log 2>&1 || exit 1
 python3 tools/pmc_read.py f16x3 > $O/${TAG}_pmc_sq_f16x3_dn_train_b32.txt || exit 1
+# ... and of the strict mode's kernels (round 5: the weight gradient's (pixel half, row pair) walk; are its LDS accesses conflict-free?)
+PMC_BATCH=32 PMC_WORKLOAD=dn_train bash tools/pmc.sh bf16x6 > $O/pmc_bf16x6.log 2>&1 || exit 1
+python3 tools/pmc_read.py bf16x6 > $O/${TAG}_pmc_sq_bf16x6_dn_train_b32.txt || exit 1
 echo "sq counters done"
 python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_default.json 2> $O/bench_default.err || exit 1
 # the by-construction-fp32 mode as a first-class line of its own (headline slot, own cpu_baseline; its PMC traffic file is above)
@@ -20,10 +23,10 @@ python3 bench.py --math bf16x6 --no-extra --steps 20 --warmup 5 > $O/${TAG}_benc
 python3 bench.py --workload sr_fwd --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_sr_fwd.json 2>/dev/null || exit 1
 python3 bench.py --workload dn_fwd --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_dn_fwd.json 2>/dev/null || exit 1
 python3 bench.py --workload sr_train --steps 4 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_sr_train.json 2>/dev/null || exit 1
-python3 bench.py --loss paper --steps 4 --warmup 1 --no-cpu-baseline --no-extra > $O/${TAG}_bench_dn_train_paper_loss.json 2>/dev/null || exit 1
-python3 bench.py --input-pipeline --batch 16 --steps 4 --warmup 1 --no-cpu-baseline --no-extra > $O/${TAG}_bench_dn_train_input_pipeline_b16.json 2>/dev/null || exit 1
-python3 bench.py --batch 16 --steps 6 --warmup 2 --no-cpu-baseline --no-extra > $O/${TAG}_bench_dn_train_b16.json 2>/dev/null || exit 1
+python3 bench.py --loss paper --steps 4 --warmup 1 --no-cpu-baseline --no-extra --no-sustained --no-psnr > $O/${TAG}_bench_dn_train_paper_loss.json 2>/dev/null || exit 1
+python3 bench.py --input-pipeline --batch 16 --steps 4 --warmup 1 --no-cpu-baseline --no-extra --no-sustained --no-psnr > $O/${TAG}_bench_dn_train_input_pipeline_b16.json 2>/dev/null || exit 1
+python3 bench.py --batch 16 --steps 6 --warmup 2 --no-cpu-baseline --no-extra --no-sustained --no-psnr > $O/${TAG}_bench_dn_train_b16.json 2>/dev/null || exit 1
 # the RCCL code path on the one GPU: a one-rank nccl process group with the reduce path forced on (parallel.collectives_on)
-XSD_FORCE_DP=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 python3 bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline --no-extra > $O/${TAG}_bench_dp1_rccl_one_gpu.json 2> $O/dp1_rccl.err || exit 1
+XSD_FORCE_DP=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 python3 bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline --no-extra --no-sustained --no-psnr > $O/${TAG}_bench_dp1_rccl_one_gpu.json 2> $O/dp1_rccl.err || exit 1
 XSD_DIST_BACKEND=gloo python3 bench.py --gpus 2 --batch 8 --steps 3 --warmup 1 --no-extra > $O/${TAG}_bench_dp2_gloo_one_gpu.json 2> $O/dp2.err || exit 1
 echo all done

@@ -318,6 +318,12 @@ __global__ __launch_bounds__(X3_THREADS) void conv3x3_s3x_kernel(const ConvParam
     }
 
     // ============================== MFMA waves ==============================
+#ifndef X3S_MPRIO
+#define X3S_MPRIO 1
+#endif
+#if X3S_MPRIO
+    __builtin_amdgcn_s_setprio(X3S_MPRIO);   // the MFMA waves are the critical path (the staging wave waits ~5k of a half-step's ~9.9k cycles at
+#endif                                       // the barrier); same device, alternating: 2.255 -> 2.241 ms per launch (-0.6 %), priority 2 the same
     f32x16 acc[2], accx[2];
     auto init_acc = [&](int j) {
         int hh = lane;                    // rebuilt from the lane id: held across the loop it is spilled
