@@ -142,6 +142,12 @@ int xsd_loss_create(const xsd_loss_config* cfg, xsd_loss_fn** out);
 void xsd_loss_destroy(xsd_loss_fn* f);
 int xsd_loss_eval(xsd_loss_fn* f, const float* dev_y, const float* dev_target, float* dev_dy_or_null, float* dev_out,
                   int B, int H, int W, void* stream);
+/* Multi-channel images ([B][C][H][W] contiguous = B*C images of H x W): tell the loss how many consecutive images form one SAMPLE
+ * (default 1).  Two terms reduce per sample, as the reference's metrics do: the Poisson term divides the element mean by the number
+ * of samples (metrics/metrics.py:30-39: `self.total += preds.size()[0]`), and MS-SSIM averages every scale's statistic over a
+ * sample's channels before the product over scales (torchmetrics: `.reshape(B, -1).mean(-1)` over C, H, W).  l1, psnr and ssim are
+ * the same either way.  xsd_loss_eval then requires B to be a multiple of `channels`. */
+int xsd_loss_set_channels(xsd_loss_fn* f, int channels);
 
 /* torch.optim.Adam(lr, betas, eps=1e-8) single fused step over flat buffers (models/model.py:241-245).
  * step is 1-based; grad_scale multiplies the gradient on read (1/world_size for data-parallel mean). */

@@ -122,38 +122,51 @@ def check_ms_ssim_size(H, W, kernel_size=13, nscales=len(BETAS)):
         raise ValueError("image too small for the MS-SSIM kernel size")
 
 
-def ms_ssim(p, t, sigma=2.5, k1=0.01, k2=0.05, betas=BETAS, want_grad=True):
+def _fold(p, t):
+    """[B,C,H,W] -> ([B*C,H,W], [B*C,H,W], C, original shape); [B,H,W] passes with C = 1.  torchmetrics filters every channel on its
+    own (grouped conv) and takes data_range over the whole tensors, so a multi-channel batch IS its B*C images -- except for
+    the per-SAMPLE reductions, which the callers do over groups of C consecutive images."""
     p = np.asarray(p, np.float64)
     t = np.asarray(t, np.float64)
+    shape = p.shape
+    C = shape[1] if p.ndim == 4 else 1
+    return p.reshape((-1,) + shape[-2:]), t.reshape((-1,) + shape[-2:]), C, shape
+
+
+def ms_ssim(p, t, sigma=2.5, k1=0.01, k2=0.05, betas=BETAS, want_grad=True):
+    """[B,H,W] or [B,C,H,W].  Per scale the statistic of a SAMPLE is the mean over its C channels (`_ssim_update`:
+    `.reshape(B, -1).mean(-1)` over C, H, W), relu, then the product over scales per sample, then the batch mean."""
+    p, t, C, shape = _fold(p, t)
     check_ms_ssim_size(*p.shape[-2:])
     ps, vals, backs = [p], [], []
     for s in range(len(betas)):
         sim, cs, back = ssim_scale(p, t, sigma, k1, k2)
-        vals.append(np.maximum(sim if s == len(betas) - 1 else cs, 0))
+        raw = (sim if s == len(betas) - 1 else cs).reshape(-1, C).mean(1)       # per sample
+        vals.append(np.maximum(raw, 0))
         backs.append(back)
         if s + 1 < len(betas):
             p, t = _pool(p), _pool(t)
             ps.append(p)
-    M = np.prod([v ** b for v, b in zip(vals, betas)], axis=0)     # per image
+    M = np.prod([v ** b for v, b in zip(vals, betas)], axis=0)     # per sample
     value = M.mean()
     if not want_grad:
         return value, None
-    B = len(M)
+    S = len(M)
     grad = None
     for s in reversed(range(len(betas))):
-        gv = np.where(vals[s] > 0, betas[s] * M / np.where(vals[s] > 0, vals[s], 1.0), 0.0) / B
+        gv = np.where(vals[s] > 0, betas[s] * M / np.where(vals[s] > 0, vals[s], 1.0), 0.0) / S
+        gv = np.repeat(gv / C, C)                                   # every channel image of the sample gets 1/C of it
         zero = np.zeros_like(gv)
         local = backs[s](gv, zero) if s == len(betas) - 1 else backs[s](zero, gv)
         grad = local if grad is None else local + _unpool(grad, ps[s].shape[-2:])
-    return value, grad
+    return value, grad.reshape(shape)
 
 
 def ssim(p, t, sigma=2.5, k1=0.01, k2=0.05, want_grad=True):
-    p = np.asarray(p, np.float64)
-    t = np.asarray(t, np.float64)
+    p, t, _, shape = _fold(p, t)         # mean over samples of the channel means = mean over all B*C images
     sim, _, back = ssim_scale(p, t, sigma, k1, k2)
     B = len(sim)
-    return sim.mean(), (back(np.full(B, 1.0 / B), np.zeros(B)) if want_grad else None)
+    return sim.mean(), (back(np.full(B, 1.0 / B), np.zeros(B)).reshape(shape) if want_grad else None)
 
 
 def psnr(p, t, want_grad=True):
@@ -199,7 +212,7 @@ def effective_weights(loss_cfg: dict, sc_dict: dict | None):
 
 
 def loss_and_grad(p, t, weights: dict, correction: float = 0.0, sigma=2.5, k1=0.01, k2=0.05):
-    """p, t: [B,H,W] (C = 1).  Returns (total, {term: value}, dtotal/dp)."""
+    """p, t: [B,H,W] or [B,C,H,W].  Returns (total, {term: value}, dtotal/dp)."""
     total, grad, values = 0.0, 0.0, {}
     for name, w in weights.items():
         if name in ("ssim", "ms_ssim"):

@@ -39,8 +39,10 @@ def _gauss(sigma, dtype):
     return torch.matmul(g.t(), g)[None, None], (size - 1) // 2
 
 
-def ssim_update(p, t, sigma=2.5, k1=0.01, k2=0.05):
-    """p, t: [B,1,H,W]; returns per-image (ssim, contrast sensitivity)"""
+def ssim_update(p, t, sigma=2.5, k1=0.01, k2=0.05, channels=1):
+    """p, t: [B,1,H,W]; returns per-image (ssim, contrast sensitivity).  channels = C: p, t hold the B*C channel images of a
+    [B,C,H,W] batch (torchmetrics filters every channel on its own: a grouped conv = the same conv over the folded images) and
+    the statistics are per SAMPLE: `.reshape(B, -1).mean(-1)` runs over C, H and W."""
     data_range = max(p.max() - p.min(), t.max() - t.min())
     c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
     kern, pad = _gauss(sigma, p.dtype)
@@ -55,7 +57,7 @@ def ssim_update(p, t, sigma=2.5, k1=0.01, k2=0.05):
     full = ((2 * mu_pt + c1) * upper) / ((mu_pp + mu_tt + c1) * lower)
     ssim_idx = full[..., pad:-pad, pad:-pad]
     cs = (upper / lower)[..., pad:-pad, pad:-pad]
-    return ssim_idx.reshape(p.shape[0], -1).mean(-1), cs.reshape(p.shape[0], -1).mean(-1)
+    return ssim_idx.reshape(p.shape[0] // channels, -1).mean(-1), cs.reshape(p.shape[0] // channels, -1).mean(-1)
 
 
 def ms_ssim(p, t, **kw):

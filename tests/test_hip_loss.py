@@ -106,26 +106,48 @@ def test_error_behaviour():
         Loss({"l1": 1.0})(torch.rand(1, 1, 8, 8), torch.rand(1, 1, 8, 8))   # CPU tensors: no fallback
 
 
-def test_multi_channel_images_fold_into_the_batch():
-    """Generators with out_channels > 1 (the reference's constructors take any, generator_rrdb.py:10-16): the element-wise terms
-    and ssim over [B, C, H, W] equal the same terms over the B*C one-channel images (what torchmetrics computes for them);
-    ms_ssim, whose per-scale channel reduction that fold does not reproduce, is refused with a message."""
-    from xmm_superres_denoise.engine import XsdError
-    from xmm_superres_denoise.utils import Loss
-    rng = np.random.default_rng(9)
-    p = rng.uniform(0, 1, size=(2, 3, 40, 56)).astype(np.float32)
-    t = rng.uniform(0, 1, size=(2, 3, 40, 56)).astype(np.float32)
-    w = {"l1": 0.4, "poisson": 0.1, "psnr": 0.2, "ssim": 0.3}
+@pytest.mark.parametrize("C", [2, 3])
+def test_multi_channel_images_reduce_per_sample(C):
+    """Generators with out_channels > 1 (the reference's constructors take any, generator_rrdb.py:10-16).  A contiguous
+    [B, C, H, W] batch is B*C one-channel images to the kernels, and the loss is told that C of them form a sample
+    (xsd_loss_set_channels): l1, psnr and ssim equal the same terms over the folded images; the Poisson term divides by the number
+    of SAMPLES (metrics/metrics.py:30-39) and MS-SSIM averages every scale's statistic over a sample's channels before the
+    product over scales (torchmetrics' `.reshape(B, -1).mean(-1)`): values and gradients of all five terms, and of the
+    reference's default composition, against the float64 oracle (itself held to torch autograd of that reduction on the CPU:
+    tests/test_loss_oracle.py)."""
+    B, H, W = 2, 304, 320
+    p3, t3 = mg.loss_inputs(B * C, H, W, 40 + C)
+    p, t = p3.reshape(B, C, H, W), t3.reshape(B, C, H, W)
+    for term in ol.TERMS:
+        tot, vals, dy = _run({term: 1.0}, 0.0, p, t)
+        v, g = ol._FUNCS[term](p, t)
+        assert abs(vals[term] - v) <= VAL_RTOL * max(1.0, abs(v)), (term, vals[term], v)
+        assert dy.shape == p.shape and np.abs(dy - g).max() <= GRAD_TOL * np.abs(g).max(), (term, float(np.abs(dy - g).max() / np.abs(g).max()))
+    # folded into the batch instead: the same for l1 / psnr / ssim (bit for bit), C times the Poisson value, another MS-SSIM
+    w = {"l1": 0.4, "psnr": 0.2, "ssim": 0.3}
     tot, vals, dy = _run(w, 0.0, p, t)
-    tot1, vals1, dy1 = _run(w, 0.0, p.reshape(6, 1, 40, 56), t.reshape(6, 1, 40, 56))
+    tot1, vals1, dy1 = _run(w, 0.0, p.reshape(B * C, 1, H, W), t.reshape(B * C, 1, H, W))
     assert tot == tot1 and vals == vals1 and np.array_equal(dy.reshape(dy1.shape), dy1)
-    # and against the float64 oracle, term by term, on the folded images
-    for term in w:
-        v, g = ol._FUNCS[term](p.reshape(6, 40, 56), t.reshape(6, 40, 56))
-        assert abs(vals[term] - v) <= VAL_RTOL * max(1.0, abs(v)), term
-    f = Loss({"ms_ssim": 1.0}, 0.0)
-    with pytest.raises(XsdError, match="ms_ssim over 3-channel"):
-        f.value_and_grad(torch.from_numpy(p).cuda(), torch.from_numpy(t).cuda())
+    _, vp, _ = _run({"poisson": 1.0}, 0.0, p, t)
+    _, vp1, _ = _run({"poisson": 1.0}, 0.0, p.reshape(B * C, 1, H, W), t.reshape(B * C, 1, H, W))
+    assert abs(vp["poisson"] - C * vp1["poisson"]) <= 1e-6 * abs(vp["poisson"])
+    # the reference's default loss (0.5 psnr + 0.5 ms_ssim, 'linear' scaling) on a multi-channel batch
+    from xmm_superres_denoise.utils import load_loss_config
+    sc, cfg = load_loss_config("linear")
+    wts, corr = ol.effective_weights(cfg.model_dump(), sc)
+    tot_o, _, g_o = ol.loss_and_grad(p, t, wts, corr)
+    tot, _, dy = _run(wts, corr, p, t)
+    assert abs(tot - tot_o) <= 1e-5 * abs(tot_o) and np.abs(dy - g_o).max() <= 1e-4 * np.abs(g_o).max()
+    # a batch that is no whole number of samples is refused by the C ABI
+    from xmm_superres_denoise.engine import _lib
+    from xmm_superres_denoise.utils import Loss
+    f = Loss({"l1": 1.0}, 0.0)
+    L = _lib.load()
+    _lib.check(L.xsd_loss_set_channels(f.h, C))
+    x = torch.rand(C + 1, 64, 64, device="cuda")
+    out = torch.empty(12, device="cuda")
+    assert L.xsd_loss_eval(f.h, x.data_ptr(), x.data_ptr(), None, out.data_ptr(), C + 1, 64, 64, None) < 0
+    assert L.xsd_loss_set_channels(f.h, 0) < 0
 
 
 def test_full_size_properties():

@@ -27,6 +27,41 @@ def test_oracle_term_matches_autograd(case, term):
     assert abs(G[f"{case}_{term}_f32_value"] - ref_v) <= 2e-6 * max(1.0, abs(ref_v))
 
 
+@pytest.mark.parametrize("C", [2, 3])
+def test_oracle_multi_channel_reductions_match_autograd(C):
+    """[B,C,H,W] batches (the reference's constructors take 3 -> 2 / 1 -> 3 generators): MS-SSIM averages every scale's statistic
+    over a sample's channels before the product over scales, the Poisson term divides by the number of SAMPLES
+    (metrics/metrics.py:30-39), ssim / psnr / l1 are what they are over the folded images -- the numpy oracle against torch
+    autograd over the torch restatement of torchmetrics' reduction (make_golden_loss.ssim_update(channels=C))."""
+    import torch
+    import torch.nn.functional as F
+    B, H, W = 2, 304, 320
+    p3, t3 = mg.loss_inputs(B * C, H, W, 40 + C)
+    p4, t4 = p3.reshape(B, C, H, W), t3.reshape(B, C, H, W)
+    tp = torch.from_numpy(p3).double()[:, None].requires_grad_(True)      # folded [B*C,1,H,W]
+    tt = torch.from_numpy(t3).double()[:, None]
+    cases = {
+        "ms_ssim": lambda: mg.ms_ssim(tp, tt, channels=C),
+        "ssim": lambda: mg.ssim_update(tp, tt, channels=C)[0].mean(),
+        "poisson": lambda: F.poisson_nll_loss(tp, tt, log_input=False, reduction="mean") / B,
+        "psnr": lambda: mg.psnr(tp, tt),
+        "l1": lambda: F.l1_loss(tp, tt),
+    }
+    for term, fn in cases.items():
+        tp.grad = None
+        v = fn()
+        v.backward()
+        g_ref = tp.grad[:, 0].numpy().reshape(B, C, H, W)
+        v_o, g_o = ol._FUNCS[term](p4, t4)
+        assert abs(v_o - v.item()) <= 1e-12 * max(1.0, abs(v.item())), term
+        assert g_o.shape == (B, C, H, W) and np.abs(g_o - g_ref).max() <= 1e-10 * np.abs(g_ref).max(), term
+    # and the per-sample reduction is NOT the per-image one (what folding the channels into the batch would compute)
+    v_fold, _ = ol.ms_ssim(p3, t3)
+    v_grp, _ = ol.ms_ssim(p4, t4)
+    assert abs(v_fold - v_grp) > 1e-8
+    assert abs(ol.poisson(p3, t3)[0] * C - ol.poisson(p4, t4)[0]) < 1e-15
+
+
 def test_create_loss_arithmetic_and_size_checks():
     sc = {"psnr": {"scaling": -0.11938872970391594, "correction": 3.6491165234001905},
           "ms_ssim": {"scaling": -2.85143997718848, "correction": 2.737382378100941}}

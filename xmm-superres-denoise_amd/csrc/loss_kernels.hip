@@ -244,6 +244,8 @@ __global__ __launch_bounds__(NT) void scale_bwd_scalars_kernel(const double* dc_
 struct CombineParams {
     const double* stat;  // [nscales][B][2]
     int nscales, B;
+    int group;           // images per SAMPLE (the channels of an NCHW batch folded into B): MS-SSIM averages a scale's statistic over them
+                         // before the product over scales, as torchmetrics does (`ssim_idx.reshape(B, -1).mean(-1)` over C, H, W)
     float betas[LOSS_MAX_SCALES];
     int ms;              // 1: MS-SSIM product; 0: plain SSIM (mean of stat[0][b][0])
     float weight;        // d total / d value
@@ -254,29 +256,39 @@ __global__ __launch_bounds__(NT) void combine_kernel(const CombineParams P)
 {
     __shared__ double red[NT];
     double acc = 0;
-    for (int b = threadIdx.x; b < P.B; b += NT) {
-        if (!P.ms) {
+    const int G = P.group, S = P.B / G;          // S samples of G images
+    if (!P.ms) {
+        for (int b = threadIdx.x; b < P.B; b += NT) {       // plain SSIM: the mean over all images = the mean over samples of their channel means
             acc += P.stat[b * 2];
             P.gup[b * 2] = P.weight / (float)P.B;
             P.gup[b * 2 + 1] = 0.f;
-            continue;
         }
+        acc = block_sum(acc, red);
+        if (threadIdx.x == 0) *P.value = (float)(acc / P.B);
+        return;
+    }
+    for (int smp = threadIdx.x; smp < S; smp += NT) {
         double v[LOSS_MAX_SCALES], M = 1.0;
         for (int s = 0; s < P.nscales; ++s) {
-            const double raw = P.stat[((long long)s * P.B + b) * 2 + (s == P.nscales - 1 ? 0 : 1)];
+            double raw = 0.0;
+            for (int c = 0; c < G; ++c) raw += P.stat[((long long)s * P.B + (long long)smp * G + c) * 2 + (s == P.nscales - 1 ? 0 : 1)];
+            raw /= G;
             v[s] = raw > 0 ? raw : 0.0;                       // normalize="relu"
             M *= pow(v[s], (double)P.betas[s]);
         }
         acc += M;
         for (int s = 0; s < P.nscales; ++s) {
-            const float g = v[s] > 0 ? (float)((double)P.betas[s] * M / v[s] * P.weight / P.B) : 0.f;
+            const float g = v[s] > 0 ? (float)((double)P.betas[s] * M / v[s] * P.weight / S / G) : 0.f;
             const bool last = s == P.nscales - 1;
-            P.gup[((long long)s * P.B + b) * 2] = last ? g : 0.f;
-            P.gup[((long long)s * P.B + b) * 2 + 1] = last ? 0.f : g;
+            for (int c = 0; c < G; ++c) {
+                P.gup[((long long)s * P.B + (long long)smp * G + c) * 2] = last ? g : 0.f;
+                P.gup[((long long)s * P.B + (long long)smp * G + c) * 2 + 1] = last ? 0.f : g;
+            }
         }
     }
     acc = block_sum(acc, red);
-    if (threadIdx.x == 0) *P.value = (float)(acc / P.B);
+    if (threadIdx.x == 0) *P.value = (float)(acc / S);
+    return;
 }
 
 // ---- transpose filter of the three gradient maps back onto the image, + pooled-scale and data_range terms ----------
@@ -482,7 +494,7 @@ int loss_check(const LossWeights& w, int B, int H, int W, const char** why)
 
 // One SSIM chain (nscales = 1: plain SSIM, 5: MS-SSIM).  ws is carved linearly; everything is stream-ordered.
 static hipError_t ssim_chain(const LossWeights& w, int term, int nscales, const float* y, const float* t, float* dy, int accumulate,
-                             float* out8, int B, int H, int W, char* ws, hipStream_t s)
+                             float* out8, int B, int group, int H, int W, char* ws, hipStream_t s)
 {
     static const float kBetas[LOSS_MAX_SCALES] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
     const Taps taps = make_taps(w.sigma);
@@ -523,7 +535,7 @@ static hipError_t ssim_chain(const LossWeights& w, int term, int nscales, const 
                            stat + (size_t)k * 2 * B);
     }
     CombineParams C;
-    C.stat = stat; C.nscales = nscales; C.B = B; C.ms = nscales > 1; C.weight = w.w[term]; C.value = out8 + 1 + term; C.gup = gup;
+    C.stat = stat; C.nscales = nscales; C.B = B; C.group = group; C.ms = nscales > 1; C.weight = w.w[term]; C.value = out8 + 1 + term; C.gup = gup;
     for (int k = 0; k < LOSS_MAX_SCALES; ++k) C.betas[k] = kBetas[k];
     hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(NT), 0, s, C);
     if (dy) {
@@ -548,9 +560,14 @@ static hipError_t ssim_chain(const LossWeights& w, int term, int nscales, const 
     return hipGetLastError();
 }
 
-hipError_t launch_loss(const LossWeights& w, const float* y, const float* t, float* dy, float* out8, int B, int H, int W, void* workspace,
-                       hipStream_t s)
+hipError_t launch_loss(const LossWeights& w, const float* y, const float* t, float* dy, float* out8, int B, int channels, int H, int W,
+                       void* workspace, hipStream_t s)
 {
+    // B images = B / channels SAMPLES of `channels` images each (an NCHW batch folded).  Two terms see samples, not images:
+    // the Poisson term (the reference divides the element mean by preds.size()[0], metrics/metrics.py:30-39) and MS-SSIM
+    // (per-sample channel mean of every scale's statistic before the product over scales)
+    if (channels < 1 || B % channels) return hipErrorInvalidValue;
+    const int samples = B / channels;
     char* ws = (char*)workspace;
     const long long n = (long long)B * H * W;
     int wrote = 0;
@@ -560,21 +577,21 @@ hipError_t launch_loss(const LossWeights& w, const float* y, const float* t, flo
         float* mse = (float*)(ws + 5 * 1024 * sizeof(double));
         const int nb = grid_for(n, NT * 8) > 1024 ? 1024 : grid_for(n, NT * 8);
         hipLaunchKernelGGL(pointwise_sums_kernel, dim3(nb), dim3(NT), 0, s, y, t, n, partial);
-        hipLaunchKernelGGL(pointwise_final_kernel, dim3(1), dim3(NT), 0, s, partial, nb, n, B, out8 + 1, out8 + 2, out8 + 3, mse, out8 + 6);
+        hipLaunchKernelGGL(pointwise_final_kernel, dim3(1), dim3(NT), 0, s, partial, nb, n, samples, out8 + 1, out8 + 2, out8 + 3, mse, out8 + 6);
         if (dy) {
             hipLaunchKernelGGL(pointwise_grad_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, y, t, dy, n, w.w[0],
-                               w.w[1] / ((float)n * (float)B), w.w[2], mse, 0);
+                               w.w[1] / ((float)n * (float)samples), w.w[2], mse, 0);
             wrote = 1;
         }
     }
     char* chain_ws = ws + (64 << 10);
     if (w.w[3] != 0.f) {
-        hipError_t e = ssim_chain(w, 3, 1, y, t, dy, wrote, out8, B, H, W, chain_ws, s);
+        hipError_t e = ssim_chain(w, 3, 1, y, t, dy, wrote, out8, B, channels, H, W, chain_ws, s);
         if (e != hipSuccess) return e;
         wrote = dy != nullptr;
     }
     if (w.w[4] != 0.f) {
-        hipError_t e = ssim_chain(w, 4, LOSS_MAX_SCALES, y, t, dy, wrote, out8, B, H, W, chain_ws, s);
+        hipError_t e = ssim_chain(w, 4, LOSS_MAX_SCALES, y, t, dy, wrote, out8, B, channels, H, W, chain_ws, s);
         if (e != hipSuccess) return e;
         wrote = dy != nullptr;
     }

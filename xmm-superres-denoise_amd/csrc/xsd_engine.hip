@@ -1411,6 +1411,7 @@ int xsd_l1_loss(xsd_engine* e, const float* dev_y, const float* dev_target, floa
 
 struct xsd_loss_fn {
     LossWeights w;
+    int channels = 1;        // images per sample (xsd_loss_set_channels)
     void* ws = nullptr;      // workspace, grown on demand
     size_t ws_bytes = 0;
 };
@@ -1439,10 +1440,18 @@ void xsd_loss_destroy(xsd_loss_fn* f)
     delete f;
 }
 
+int xsd_loss_set_channels(xsd_loss_fn* f, int channels)
+{
+    if (!f || channels < 1 || channels > 1024) return fail(XSD_ERR_ARG, "xsd_loss_set_channels: channels must be 1..1024");
+    f->channels = channels;
+    return XSD_OK;
+}
+
 int xsd_loss_eval(xsd_loss_fn* f, const float* dev_y, const float* dev_target, float* dev_dy_or_null, float* dev_out8, int B, int H,
                   int W, void* stream)
 {
     if (!f || !dev_y || !dev_target || !dev_out8) return fail(XSD_ERR_ARG, "bad argument");
+    if (B < 1 || B % f->channels) return fail(XSD_ERR_ARG, "xsd_loss_eval: %d images are no whole number of %d-channel samples (xsd_loss_set_channels)", B, f->channels);
     const char* why = nullptr;
     if (loss_check(f->w, B, H, W, &why)) return fail(XSD_ERR_ARG, why);
     const size_t need = loss_workspace_bytes(B, H, W);
@@ -1453,7 +1462,7 @@ int xsd_loss_eval(xsd_loss_fn* f, const float* dev_y, const float* dev_target, f
         if (hipMalloc(&f->ws, need) != hipSuccess) return fail(XSD_ERR_NOMEM, "loss workspace allocation failed");
         f->ws_bytes = need;
     }
-    HIPCHK(launch_loss(f->w, dev_y, dev_target, dev_dy_or_null, dev_out8, B, H, W, f->ws, (hipStream_t)stream));
+    HIPCHK(launch_loss(f->w, dev_y, dev_target, dev_dy_or_null, dev_out8, B, f->channels, H, W, f->ws, (hipStream_t)stream));
     return XSD_OK;
 }
 

@@ -22,7 +22,8 @@ size_t loss_workspace_bytes(int B, int H, int W);
 int loss_check(const LossWeights& w, int B, int H, int W, const char** why);
 // out8 (device, LOSS_OUT_FLOATS floats): [0] total, [1..5] l1, poisson, psnr, ssim, ms_ssim (0 for inactive terms),
 // [6] mean squared error, [7] min(target), [8] max(target) (written when any of l1/poisson/psnr is active); dy may be null
-hipError_t launch_loss(const LossWeights& w, const float* y, const float* t, float* dy, float* out8, int B, int H, int W, void* workspace,
-                       hipStream_t s);
+// B images of H x W = B / channels samples (NCHW folded): the Poisson term and MS-SSIM reduce per sample
+hipError_t launch_loss(const LossWeights& w, const float* y, const float* t, float* dy, float* out8, int B, int channels, int H, int W,
+                       void* workspace, hipStream_t s);
 
 } // namespace xsd

@@ -158,21 +158,21 @@ class Loss:
             raise XsdError(f"shape mismatch {tuple(preds.shape)} vs {tuple(target.shape)}")
         if preds.dim() == 4:
             # [B, C, H, W]: the kernels take one-channel images, so the channels fold into the batch (a contiguous NCHW tensor is
-            # B*C images).  That is exactly what torchmetrics computes for the element-wise terms (l1, poisson, mse -> psnr: means
-            # over all elements) and for ssim (per-image mean over C, H, W, then the mean over images: equal-sized groups).
-            # ms_ssim is the exception: torchmetrics averages each scale's contrast term over the CHANNELS of an image before the
-            # product over scales, which a per-channel product does not reproduce -- refused rather than approximated.
+            # B*C images) and the loss is told how many images form a sample (xsd_loss_set_channels): l1, psnr (means over all
+            # elements) and ssim (mean over samples of the channel means) do not care; the Poisson term divides by the number of
+            # SAMPLES (metrics/metrics.py:30-39) and MS-SSIM averages each scale's statistic over a sample's channels before the
+            # product over scales, as torchmetrics does.
             B, C, H, W = preds.shape
-            if C > 1 and self.weights.get("ms_ssim", 0.0) != 0.0:
-                raise XsdError(f"ms_ssim over {C}-channel images is not implemented (torchmetrics reduces an image's channels jointly per "
-                               "scale); use the l1 / poisson / psnr / ssim terms for multi-channel generators")
+            channels = C
             B = B * C
         elif preds.dim() == 3:
             B, H, W = preds.shape
+            channels = 1
         else:
             raise XsdError(f"expected [B,C,H,W] or [B,H,W], got {tuple(preds.shape)}")
         out = torch.empty(12, device=preds.device, dtype=torch.float32)
         dy = torch.empty_like(preds) if want_grad else None
+        check(self.L.xsd_loss_set_channels(self.h, channels))
         check(self.L.xsd_loss_eval(self.h, preds.data_ptr(), target.data_ptr(), dy.data_ptr() if want_grad else None,
                                    out.data_ptr(), B, H, W, _stream_ptr(preds.device)))
         return out, dy
