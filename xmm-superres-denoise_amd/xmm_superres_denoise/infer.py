@@ -141,7 +141,8 @@ def infer_file(fits_path, model, det_mask: torch.Tensor | None, out_dir, lr_res:
         if data.dtype.itemsize == 4 and data.dtype.kind in "if" else torch.from_numpy(data.astype(np.float32))[None].to(device)
     big_endian = data.dtype.itemsize == 4 and data.dtype.kind in "if" and data.dtype.byteorder == ">"
     x = compose_input(raw, None, None, det_mask, lr_res, lr_max, stretch, big_endian=big_endian)
-    y = model(x)
+    with torch.no_grad():       # the inference plan (9 recycled planes), not the training plan that keeps every activation
+        y = model(x)
     res_mult = y.shape[-1] // x.shape[-1]
     y_phys = normalize(y.contiguous(), hr_max if res_mult > 1 else lr_max, stretch, inverse=True)[0, 0].cpu().numpy()
     os.makedirs(out_dir, exist_ok=True)
