@@ -561,6 +561,7 @@ def main():
                  "max_abs_output_diff_vs_" + args.math: err, "note": "not the headline: the strict mode, reported for comparison"}
         if pwx.summary() is not None:
             extra["power"] = pwx.summary()
+            extra["power"]["joules_per_tile"] = round(extra["power"]["avg_w"] * (dte / args.steps) / B, 3)
         if profe is not None and profe[0]["launches"] > 0:
             xs = eng.probe_mfma_stream("f16" if xm == "f16x3" else "bf16", args.sustained_seconds) if (xm in MATH_PRODUCTS and not args.no_sustained) else None
             extra["roofline"] = roofline_block(xm, profe, B, kind, train, world, B * world * args.steps / dte, NF == 32, xs)
@@ -589,6 +590,8 @@ def main():
         if prof is not None and prof[0]["launches"] > 0:
             out["roofline"] = roofline_block(args.math, prof, B, kind, train, world, tiles / dt, NF == 32, sustained)
         if power is not None:
+            # the step runs at the package cap, so the rate IS watts / joules per tile: the figure a kernel change has to move
+            power["joules_per_tile"] = round(power["avg_w"] * (dt / args.steps) / B, 3)
             out["power"] = power
         if train:
             out["comm_ms_exposed"] = None if comm_ms is None else round(comm_ms, 4)     # rank 0's; every rank's in per_rank

@@ -142,6 +142,7 @@ def test_bench_line_reports_package_power_and_clock():
         pytest.skip("no readable amdgpu hwmon files on this box")
     assert pw["cap_w"] and 0.9 < pw["frac_of_cap"] <= 1.05, pw      # sampled from the post-warm-up synchronize to the closing one: no idle samples
     assert 500 <= pw["sclk_mhz"] <= 2600 and pw["samples"] >= 3, pw
+    assert abs(pw["joules_per_tile"] - pw["avg_w"] * d["ms_per_step"] * 1e-3 / d["config"]["per_gpu_batch"]) < 0.01 and 5 < pw["joules_per_tile"] < 30, pw
     # the roof the power cap leaves, measured in the bench process: the conv's bare MFMA stream sustains 0.5 - 0.8 of the nominal peak
     r = d["roofline"]
     assert 0.4 * r["peak"] < r["sustained_peak"] < 0.95 * r["peak"], r
