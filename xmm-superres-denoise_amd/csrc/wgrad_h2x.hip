@@ -214,7 +214,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_h2x_kernel(const WgradParams
         // Round 5: the staging waves are the longer role since the column ring (stamps at the bench batch: their rounds 5.2k cycles per
         // tile, the MFMA waves wait 1.5k per tile at the barrier): they issue ahead.  Same device, alternating: 6.075 -> 5.990 ms
         // per block launch (-1.4 %; priority 3 the same), step +0.5 %.  (Handing the two-row LDS -> LDS copy to the waiting MFMA
-        // waves instead measured +1.1 % per launch: tools/attic/wgrad_h2x_mfma_wave_halo_copy.hip.txt.)
+        // waves instead measured +1.1 % per launch: tools/attic/wgrad_h2x_mfma_wave_halo_copy.patch.)
         __builtin_amdgcn_s_setprio(V3_LPRIO);
         const int lt = tid;
         const PlaneIn xp = P.x[j];

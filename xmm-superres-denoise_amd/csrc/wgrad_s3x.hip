@@ -294,7 +294,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
         // operand of the lower one: 12 (dx, h) steps fetch 36 X fragments + 6 G fragments per wave and tile instead of 54 + 6
         // (LDS fragment reads per tile and CU: 480 -> 336 ds_read_b64_tr_b16, -30 %), for the same 108 MFMAs.  The images, the
         // staging waves and the final reduction (four partial sums per tap) are unchanged.  Same device: 10.19 -> 9.95 ms per block
-        // launch.  (Tried on top and removed, tools/attic/wgrad_s3x_rotated_walk.hip.txt: the walk rotated across the barrier -- a
+        // launch.  (Tried on top and removed, tools/attic/wgrad_s3x_rotated_walk.patch: the walk rotated across the barrier -- a
         // tile's last six MFMAs issued behind the next tile's first 18 reads to cover their round trip: +0.4 % per launch; with a
         // branch on "is there a next tile" the compiler waits for lgkmcnt(0) in front of the deferred MFMAs: +1.8 %.)
         const int mf = wv & 1, rp = wv >> 1;
