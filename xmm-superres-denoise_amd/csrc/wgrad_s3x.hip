@@ -18,7 +18,6 @@
 //   * waves 4..7 multiply tile t: wave 4+r owns tile row r, nine 32x32 accumulators (one per tap) held across all tiles of
 //     the workgroup; their stream is ds_read_b64_tr_b16 + v_mfma only.
 // One barrier per tile.  Two waves per SIMD -> 256 registers per wave.
-#include <type_traits>
 #include "xsd_kernels.h"
 #include "xsd_split.h"
 
@@ -41,39 +40,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef V3_PAIR
 #define V3_PAIR 1      // MFMA waves own (pixel half, row pair) instead of a tile row (round 5; -DV3_PAIR=0: the round-4 walk, for A/Bs)
 #endif
-constexpr int V3_TH = 4;                                              // tile rows
+constexpr int V3_TH = 4;                                              // tile rows = MFMA waves
 constexpr int V3_LT = 256;                                            // staging threads (waves 0..3)
-#if V3_PAIR == 2
-constexpr int V3_MW = 8;                                              // MFMA waves: (pixel half, row pair) x (taps 0..4 | taps 5..8), two per SIMD
-#else
-constexpr int V3_MW = 4;                                              // MFMA waves: one per SIMD
-#endif
-constexpr int V3_THREADS = V3_LT + 64 * V3_MW;
-// V3_PAIR == 2: which (dx, halo row) steps a wave of tap group T walks, and which of ITS accumulators (local index; -1: none) the
-// fragment feeds for the upper row (tap dy = h) and for the lower row (tap dy = h - 1).  T = 0 holds taps 0..4, T = 1 taps 5..8.
-__host__ __device__ constexpr int s3_nsteps(int T) { return T == 0 ? 8 : 7; }
-__host__ __device__ constexpr int s3_dx(int T, int st) { return T == 0 ? st % 3 : (st + 2) % 3; }
-__host__ __device__ constexpr int s3_h(int T, int st) { return T == 0 ? st / 3 : (st + 5) / 3; }
-__host__ __device__ constexpr int s3_tap_local(int T, int dy, int dx)      // local accumulator of tap (dy, dx) in group T, -1 if it is the other group's
-{
-    const int tap = 3 * dy + dx;
-    return (dy < 0 || dy > 2) ? -1 : (T == 0 ? (tap < 5 ? tap : -1) : (tap >= 5 ? tap - 5 : -1));
-}
-__host__ __device__ constexpr int s3_up(int T, int st) { return s3_tap_local(T, s3_h(T, st), s3_dx(T, st)); }
-__host__ __device__ constexpr int s3_lo(int T, int st) { return s3_tap_local(T, s3_h(T, st) - 1, s3_dx(T, st)); }
-constexpr bool s3_deal_covers_every_product()
-{
-    int hits[9][2] = {};      // [tap][row of the pair]
-    for (int T = 0; T < 2; ++T)
-        for (int st = 0; st < s3_nsteps(T); ++st) {
-            if (s3_up(T, st) < 0 && s3_lo(T, st) < 0) return false;      // no step without work
-            if (s3_up(T, st) >= 0) ++hits[s3_up(T, st) + 5 * T][0];
-            if (s3_lo(T, st) >= 0) ++hits[s3_lo(T, st) + 5 * T][1];
-        }
-    for (int t = 0; t < 9; ++t) if (hits[t][0] != 1 || hits[t][1] != 1) return false;
-    return true;
-}
-static_assert(s3_deal_covers_every_product(), "every (tap, row) product is formed by exactly one wave type");
+constexpr int V3_THREADS = V3_LT + 64 * V3_TH;                        // 512
 constexpr int V3_HPX = (V3_TH + 2) * HALO_W;                          // 204 halo pixels
 constexpr int V3_X_SLOTS = V3_HPX * 8;                                // 1632 (pixel, channel quad) slots
 constexpr int V3_X_ROUNDS = (V3_X_SLOTS + V3_LT - 1) / V3_LT;         // 7
@@ -108,7 +77,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wid < 4;       // wave-uniform role (waves 0..3 stage, waves 4.. multiply)
+    const bool loader = wid < 4;       // wave-uniform role
     const int h = lane >> 5;
     const int l31 = lane & 31;
 
@@ -156,11 +125,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
 #else
 #define V3_LTICK(i) do { } while (0)
 #endif
-#if V3_PAIR == 2
-    f32x16 acc[5];      // this wave's taps: group 0 = taps 0..4, group 1 = taps 5..8
-#else
     f32x16 acc[9];
-#endif
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f}; // staging thread: its 4 channels (lt & 7) of the G tiles it stages
 
     if (loader) {
@@ -313,7 +278,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
         // are co-critical and the same switch was zero-sum.)
         __builtin_amdgcn_s_setprio(V3S_MPRIO);
 #pragma unroll
-        for (int k = 0; k < (V3_PAIR == 2 ? 5 : 9); ++k)
+        for (int k = 0; k < 9; ++k)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
         // per-lane base of the transposing reads: lane i of a 16-lane group addresses block row q = i>>2 (pixel) and
@@ -322,55 +287,7 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
         const int lane_off = (8 * h + (i16 >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (i16 & 3) * 8;
         lds_barrier();                                                                     // (P)
         V3_TICK(1);
-#if V3_PAIR == 2
-        // Two MFMA waves per SIMD: the (pixel half, row pair) walk below, its nine taps dealt to TWO waves (taps 0..4 | 5..8; five
-        // accumulators each, so 12 waves fit 168 registers): while one wave waits for its first fragments after the barrier, or at
-        // the barrier itself, the other keeps the SIMD's matrix pipe fed.  Price: the G fragments are read by both waves and three
-        // X fragments twice: 15 + 4 fragment sets per (pixel half, row pair) and tile instead of 12 + 2.
-        const int grp = wv & 3, mf = grp & 1, rp = grp >> 1;
-        auto walk2 = [&](auto TV) {
-            constexpr int T = decltype(TV)::value;
-            constexpr int NS = s3_nsteps(T);
-#pragma unroll 1
-            for (int k = 0; k < my_tiles; ++k) {
-                const char* xbase = smem + (k & 1) * V3_BUF + (2 * rp) * (HALO_W * 64) + 16 * mf * 64 + lane_off;
-                const char* gbase = smem + (k & 1) * V3_BUF + V3_G_OFF + (2 * rp) * (TILE_W * 64) + 16 * mf * 64 + lane_off;
-                bf16x8 g[2][3], x[2][3];
-                auto load_g = [&](int q, bf16x8 (&d)[3]) {
-#pragma unroll
-                    for (int term = 0; term < 3; ++term) d[term] = v3_tr_frag(gbase, term * V3_GT + q * (TILE_W * 64));
-                };
-                auto load_x = [&](int st, bf16x8 (&d)[3]) {
-#pragma unroll
-                    for (int term = 0; term < 3; ++term) d[term] = v3_tr_frag(xbase, term * V3_XT + (s3_h(T, st) * HALO_W + s3_dx(T, st)) * 64);
-                };
-                auto mac6 = [&](f32x16& a, const bf16x8 (&xx)[3], const bf16x8 (&gg)[3]) {
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xx[2], gg[0], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xx[0], gg[2], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xx[1], gg[1], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xx[1], gg[0], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xx[0], gg[1], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xx[0], gg[0], a, 0, 0, 0);
-                };
-                load_g(0, g[0]);      // both groups start with upper-row taps (group 1's first step (dx 2, h 1) is tap 5 of the upper row)
-                load_x(0, x[0]);
-                load_g(1, g[1]);
-#pragma unroll
-                for (int st = 0; st < NS; ++st) {
-                    if (st + 1 < NS) load_x(st + 1, x[(st + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (s3_up(T, st) >= 0) mac6(acc[s3_up(T, st) >= 0 ? s3_up(T, st) : 0], x[st & 1], g[0]);
-                    if (s3_lo(T, st) >= 0) mac6(acc[s3_lo(T, st) >= 0 ? s3_lo(T, st) : 0], x[st & 1], g[1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                V3_TICK(0);
-                lds_barrier();
-                V3_TICK(1);
-            }
-        };
-        if ((wv >> 2) == 0) walk2(std::integral_constant<int, 0>{});
-        else walk2(std::integral_constant<int, 1>{});
-#elif V3_PAIR
+#if V3_PAIR
         // Round 5: a wave owns a PIXEL HALF of a ROW PAIR (mf = wv & 1: pixels 16 mf .. 16 mf + 15 = the K of a 32x32x16 MFMA; rows
         // 2 rp, 2 rp + 1, rp = wv >> 1) instead of a whole tile row.  The nine accumulators are sums over pixels, so they serve both
         // rows, and the fragment of halo row h at column offset dx is the dy = h operand of the upper row AND the dy = h - 1
@@ -379,7 +296,11 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
         // staging waves and the final reduction (four partial sums per tap) are unchanged.  Same device: 10.19 -> 9.95 ms per block
         // launch.  (Tried on top and removed, tools/attic/wgrad_s3x_rotated_walk.patch: the walk rotated across the barrier -- a
         // tile's last six MFMAs issued behind the next tile's first 18 reads to cover their round trip: +0.4 % per launch; with a
-        // branch on "is there a next tile" the compiler waits for lgkmcnt(0) in front of the deferred MFMAs: +1.8 %.)
+        // branch on "is there a next tile" the compiler waits for lgkmcnt(0) in front of the deferred MFMAs: +1.8 %.  And TWO MFMA
+        // waves per SIMD -- the nine taps dealt 5 | 4 to two waves of five accumulators each, 12 waves at 134 registers, so that one
+        // wave's bubble at the barrier is the other's matrix time: parity green, 9.206 -> 9.211 ms per block launch at a 1.5 % LOWER
+        // clock (tools/attic/wgrad_s3x_two_mfma_waves_per_simd.patch).  Fewer stall cycles at the same milliseconds: after the
+        // priority change this kernel, too, sits at the package's energy bound, and schedules have nothing left to give.)
         const int mf = wv & 1, rp = wv >> 1;
 #pragma unroll 1
         for (int k = 0; k < my_tiles; ++k) {
@@ -481,16 +402,6 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
     float* outp = P.partial + (P.npairs > 0 ? ((long long)part * P.npairs + slot) * 9 : (((long long)part * P.n_g + n) * P.n_in + j) * 9) * 1024;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-#if V3_PAIR == 2
-        if (!loader && ((wid - 4) >> 2) == (tap < 5 ? 0 : 1)) {      // the four waves that hold this tap, slab = their (pixel half, row pair)
-            const int wv = (wid - 4) & 3;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int ci = (i & 3) + 8 * (i >> 2) + 4 * h;
-                red[wv * 1024 + ci * 32 + l31] = acc[tap < 5 ? tap : tap - 5][i];
-            }
-        }
-#else
         if (!loader) {
             const int wv = wid - 4;
 #pragma unroll
@@ -499,7 +410,6 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
                 red[wv * 1024 + ci * 32 + l31] = acc[tap][i];
             }
         }
-#endif
         __syncthreads();
         for (int e = tid; e < 1024; e += V3_THREADS) {
             float sacc = 0.f;
