@@ -320,6 +320,10 @@ __global__ __launch_bounds__(V3_THREADS) void wgrad_s3x_kernel(const WgradParams
             auto mac6 = [&](f32x16& a, const bf16x8 (&xx)[3], const bf16x8 (&gg)[3]) {
                 // Running accumulators take every product: 12 roundings per tile row and tap, against 32 for an fp32 fma chain
                 // over the same 32 pixels (single-layer error vs float64: tools/dbg_layer.py).
+#ifdef V3S_NOMFMA   // energy experiment (tools/power_table_strict.sh): the whole kernel but its matrix instructions -- results are garbage
+                asm volatile("" :: "v"(xx[0]), "v"(xx[1]), "v"(xx[2]), "v"(gg[0]), "v"(gg[1]), "v"(gg[2]), "v"(a));
+                return;
+#endif
                 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xx[2], gg[0], a, 0, 0, 0);
                 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xx[0], gg[2], a, 0, 0, 0);
                 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xx[1], gg[1], a, 0, 0, 0);
