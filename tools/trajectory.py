@@ -33,7 +33,7 @@ The bar (tests/test_hip_trajectory.py asserts it), for every engine mode, at ste
     16 significant bits are at 1e-3 dB / 3e-5, to 20 bits at 1e-4 dB (tools/trajectory_sigbits_probe.py): the run carries that
     16-bit arithmetic as a NEGATIVE CONTROL leg, which must fail this bar.  (The review's 0.01 dB would not catch it.)
   * later checkpoints: |loss - loss_f64| and |PSNR - PSNR_f64| <= max(2 x the largest such distance among the yard-sticks (torch
-    float32 on the host cores and on the GPU, the ulp-perturbed float64 runs), an allowance of 0.01 dB / 1e-5 up to step 50 and
+    float32 on the host cores and on the GPU, the ulp-perturbed float64 runs), an allowance of 0.01 dB / 1e-4 up to step 50 and
     1 dB / 5e-3 beyond).  Past the onset (steps 50 - 60: the distance grows 20 x per 10 steps) a distance is one draw from a wide
     distribution, and "2 x the largest of six yard-sticks" alone would fail a legitimate run about every tenth time.
 `report()` also lists which runs meet 0.01 dB at the last checkpoint (for the record; the yard-sticks' own figures beside it).
@@ -197,7 +197,7 @@ CONTROL = "control_16bit"   # the negative control leg: torch float32 with 16-bi
 # modes end 0.02 - 1.6 dB apart); "2 x the largest of a handful of yard-sticks" alone would fail a legitimate run every ~10th time.
 # So the relative bar carries an absolute allowance per regime: what a run may differ by without that meaning anything.
 PSNR_FLOOR_DB = lambda c: 0.01 if c <= 50 else 1.0
-LOSS_FLOOR = lambda c: 1e-5 if c <= 50 else 5e-3
+LOSS_FLOOR = lambda c: 1e-4 if c <= 50 else 5e-3        # (0.01 dB is 0.23 % of the mse: 1e-4 of a loss of 0.03 is the same size)
 
 
 def yard_sticks(res):
