@@ -25,7 +25,15 @@ runs as a rank.  XSD_DIST_BACKEND=gloo rehearses the multi-rank path on a box wi
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     : the dominant kernel's algorithmic FLOP (or bytes) / its average HIP-event launch time inside the timed
-                 region against the peak that binds the mode (MI355X_MICROARCH.md), and
+                 region against the peak that binds the mode (MI355X_MICROARCH.md); `sustained_peak` / `frac_of_sustained`: the
+                 same against what THIS device sustains on the conv's bare MFMA stream, measured in this process after the timed
+                 region (xsd_probe_mfma_stream: the roof the 1400 W package cap leaves of the nominal peak),
+  power        : watts, clock, fraction of the cap and joules per tile over the timed region (sysfs, sampled between the two
+                 synchronizes),
+  psnr_delta_db: the second half of BASELINE's metric -- PSNR(engine in the timed math mode) - PSNR(reference) on the two
+                 example_data tiles of tests/golden/example_data.npz, identical seeded weights, outside the timed region,
+  comm_ms_exposed / per_rank (N > 1): what the compute stream waited for the gradient exchange; every rank's own step time,
+                 device clock, watts and sustained matrix rate -- a < N x curve separates device spread from communication,
   cpu_baseline : the same train step (B=1) through oracle/oracle.py's torch restatement on the host cores (1 warm-up step,
                  then best of 3; every sample recorded).
 """
