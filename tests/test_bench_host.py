@@ -79,3 +79,26 @@ def test_power_watch_reports_this_jobs_devices_by_pci_address(tmp_path):
         time.sleep(0.3)
     s = pw.summary()
     assert abs(s["avg_w"] - 1399.0) < 0.5 and "BUSIEST" in s["source"]
+
+
+def test_scale_report_decomposes_an_efficiency(tmp_path):
+    """tools/scale_report.py: efficiency = mean rank rate x slowest rank's share x barrier, from the per_rank block of bench.py's lines"""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scale_report as sr
+    one = {"metric": "m", "value": 128.0, "n_gpus": 1, "ms_per_step": 250.0, "comm_ms_exposed": 0.0}
+    ms = [250.0, 255.0, 260.0, 270.0]
+    four = {"metric": "m", "value": 4 * 32 / 0.271, "n_gpus": 4, "ms_per_step": 271.0,
+            "per_rank": {"ms_per_step": ms, "sclk_mhz": [1700, 1650, 1620, 1580], "sustained_mfma_tflops": [1520, 1500, 1480, 1450],
+                         "comm_ms_exposed": [0.1, 0.12, 0.2, 0.05]}}
+    p1, p4 = os.path.join(tmp_path, "n1.json"), os.path.join(tmp_path, "n4.json")
+    open(p1, "w").write("noise before\n" + json.dumps(one) + "\n")
+    open(p4, "w").write(json.dumps({"run": {"stdout_tail": json.dumps(four) + "\n"}}))      # a driver record with the line inside a string
+    by_n = sr.load([p1, p4])
+    assert sorted(by_n) == [1, 4]
+    text = sr.report(by_n)
+    row = [l for l in text.splitlines() if l.strip().startswith("4 ")][0].split()
+    eff, mean_rate, slow, barrier, comm = (float(v) for v in row[2:7])
+    assert abs(eff - four["value"] / (4 * 128.0)) < 1e-3
+    assert abs(mean_rate - 250.0 / (sum(ms) / 4)) < 1e-3 and abs(slow - (sum(ms) / 4) / 270.0) < 1e-3 and abs(barrier - 270.0 / 271.0) < 1e-3
+    assert abs(eff - mean_rate * slow * barrier) < 2e-3 and comm == 0.2
