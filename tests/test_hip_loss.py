@@ -150,6 +150,33 @@ def test_multi_channel_images_reduce_per_sample(C):
     assert L.xsd_loss_set_channels(f.h, 0) < 0
 
 
+def test_default_loss_trains_a_multi_channel_generator():
+    """What the multi-channel reductions are for: the reference's default loss (0.5 psnr + 0.5 ms_ssim, 'linear' scaling) now trains
+    a generator with several image channels (the reference's constructors take them: 3 -> 2 here, SR 2x).  First step: loss value and
+    d loss / d y against the float64 oracle on the engine's own output; then a few Adam steps on the fixed batch lower the loss."""
+    from xmm_superres_denoise.models import GeneratorRRDB_SR
+    from xmm_superres_denoise.parallel import DataParallelTrainer
+    from xmm_superres_denoise.utils import create_loss, load_loss_config
+    torch.manual_seed(4)
+    m = GeneratorRRDB_SR(3, 2, 32, 1, num_upsample=1).cuda()
+    sc, cfg = load_loss_config("linear")
+    fn = create_loss(sc, cfg)
+    tr = DataParallelTrainer(m, lr=1e-3, loss=fn)
+    p3, t3 = mg.loss_inputs(2 * 3, 152, 160, 71)
+    x = torch.from_numpy(p3.reshape(2, 3, 152, 160)).cuda()
+    _, t2 = mg.loss_inputs(2 * 2, 304, 320, 72)
+    t = torch.from_numpy(t2.reshape(2, 2, 304, 320)).cuda()
+    with torch.no_grad():
+        y0 = m(x)
+    tot, dy = fn.value_and_grad(y0.contiguous(), t)
+    wts, corr = ol.effective_weights(cfg.model_dump(), sc)
+    tot_o, _, g_o = ol.loss_and_grad(y0.cpu().numpy(), t.cpu().numpy(), wts, corr)
+    assert abs(tot.item() - tot_o) <= 1e-5 * abs(tot_o) and np.abs(dy.cpu().numpy() - g_o).max() <= 1e-4 * np.abs(g_o).max()
+    losses = [float(tr.train_step(x, t)) for _ in range(8)]
+    assert abs(losses[0] - tot_o) <= 1e-5 * abs(tot_o)
+    assert losses[-1] < losses[0] - 0.02 * abs(losses[0]), losses
+
+
 def test_full_size_properties():
     """512 x 512, batch 8: identical images give ssim = ms_ssim = 1 and a vanishing gradient; the composed value is
     linear in the weights; the result is bit-reproducible (deterministic reductions)."""
