@@ -71,7 +71,7 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(kind: str, train: bool, repeats: int = 3):
+def cpu_baseline(kind: str, train: bool, repeats: int = 3, tile: int = TILE):
     """Reference op graph on the host CPU (torch restatement, pinned to the reference by tests/test_oracle_pinned.py): B=1
     512x512 steps on all host cores -- one untimed warm-up step at full size (thread pool, oneDNN primitives, allocator),
     then `repeats` timed steps; the best is `value`, every sample is recorded."""
@@ -83,9 +83,9 @@ def cpu_baseline(kind: str, train: bool, repeats: int = 3):
     m = GeneratorRRDB_DN(1, 1, 32, 4) if kind == "dn" else GeneratorRRDB_SR(1, 1, 32, 4, num_upsample=1)
     state = {k: v.detach().clone().requires_grad_(train) for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(0)
-    x = torch.rand((1, 1, TILE, TILE), generator=g)
+    x = torch.rand((1, 1, tile, tile), generator=g)
     s = 2 if kind == "sr" else 1
-    t = torch.rand((1, 1, TILE * s, TILE * s), generator=torch.Generator().manual_seed(1))
+    t = torch.rand((1, 1, tile * s, tile * s), generator=torch.Generator().manual_seed(1))
     opt = torch.optim.Adam(list(state.values()), lr=1e-4, betas=(0.9, 0.999)) if train else None
 
     def one_step():
@@ -106,7 +106,7 @@ def cpu_baseline(kind: str, train: bool, repeats: int = 3):
     best = min(samples)
     return {"value": 1.0 / best, "unit": "tiles/s", "cores": cores, "kind": "port",
             "samples_s": [round(v, 3) for v in samples], "warmup_s": round(warm, 3),
-            "sample": f"{'train step (fwd+L1+bwd+Adam)' if train else 'forward'} of 1 tile 1x{TILE}x{TILE}, torch-CPU restatement of the "
+            "sample": f"{'train step (fwd+L1+bwd+Adam)' if train else 'forward'} of 1 tile 1x{tile}x{tile}, torch-CPU restatement of the "
                       f"reference graph (oracle/oracle.py:torch_forward): 1 warm-up + best of {repeats} ({best:.1f} s)"}
 
 
@@ -237,19 +237,22 @@ MATHS = {
               "average launch time here is over all of them)"),
 }
 DEFAULT_MATH = "f16x3"
+# include/xsd.h: xsd_profile_read classes.  0 / 1 are MFMA-bound; the others are HBM-bound ("report both GB/s vs 8 TB/s
+# and MFMA-util ... per kernel; never substitute one for the other")
+PROFILE_CLASSES = ("conv", "wgrad", "edge_expand", "edge_reduce", "edge_wgrad", "l1_loss", "adam", "clamp_bwd", "plane_amax")
 MATH_PRODUCTS = {"bf16x6": 6, "f16x3": 3}   # 16-bit MFMAs per fp32 product
 STEP_BYTES = {("dn", True): 117020.0, ("dn", False): 33420.0, ("sr", True): 124224.0, ("sr", False): 35476.0}   # SURVEY 8(d), per LR pixel
 STEP_FLOP = {("dn", True): 2.62e12, ("dn", False): 8.749e11, ("sr", True): 2.74e12, ("sr", False): 9.140e11}   # per tile
 
 
-def roofline_block(math, prof, batch, kind, train, world, tiles_per_s, shipped_width=True, sustained=None):
+def roofline_block(math, prof, batch, kind, train, world, tiles_per_s, shipped_width=True, sustained=None, tile=TILE):
     """roofline of the dominant kernel (the conv: forward + input-gradient launches) from the HIP-event records of the timed
     region; `prof` = {0: conv totals, 1: weight-gradient totals} (Engine.profile_read)."""
     k = prof[0]
     sec = k["ms"] * 1e-3
     tf = k["flop"] / sec / 1e12
     gbs = k["bytes"] / sec / 1e9
-    pmc_ok = train and kind == "dn" and world == 1 and shipped_width
+    pmc_ok = train and kind == "dn" and world == 1 and shipped_width and tile == TILE
     traffic, tfile = pmc_traffic(math, batch, "conv") if pmc_ok else (None, None)
     hb = {"achieved": gbs, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBPS}
     if math == "fp32":   # exact fp32 MFMA: compute-bound by 4-5x (DESIGN.md section 4)
@@ -277,11 +280,24 @@ def roofline_block(math, prof, batch, kind, train, world, tiles_per_s, shipped_w
         wt, wfile = pmc_traffic(math, batch, "wgrad") if pmc_ok else (None, None)
         roof["wgrad_kernel"] = {"achieved_TFLOPs": w["flop"] / wsec / 1e12, "achieved_GBps": w["bytes"] / wsec / 1e9,
                                 "launches": w["launches"], "avg_launch_ms": w["ms"] / w["launches"], "traffic": wt, "traffic_from": wfile}
+    # the HBM-bound kernels of the step (profile classes 2..): algorithmic bytes / HIP-event time per kernel against 8 TB/s
+    edge = {}
+    for k in range(2, len(PROFILE_CLASSES)):
+        r = prof.get(k)
+        if r and r["launches"] > 0 and r["ms"] > 0:
+            g = r["bytes"] / (r["ms"] * 1e-3) / 1e9
+            edge[PROFILE_CLASSES[k]] = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g / HBM_PEAK_GBPS,
+                                        "launches": r["launches"], "avg_launch_us": 1e3 * r["ms"] / r["launches"],
+                                        "algorithmic_bytes_per_launch": r["bytes"] / r["launches"]}
+    if edge:
+        tot_ms = sum(prof[k]["ms"] for k in prof)
+        edge["share_of_profiled_kernel_time"] = sum(prof[k]["ms"] for k in range(2, len(PROFILE_CLASSES)) if k in prof) / tot_ms if tot_ms > 0 else None
+        roof["edge"] = edge
     if not shipped_width:
         return roof
     # whole-step algorithmic bytes / flops per tile (fp32 counting rule) x tiles/s against the peaks
-    step_bytes = STEP_BYTES[(kind, train)] * TILE * TILE
-    step_flop = STEP_FLOP[(kind, train)]
+    step_bytes = STEP_BYTES[(kind, train)] * tile * tile
+    step_flop = STEP_FLOP[(kind, train)] * (tile * tile) / float(TILE * TILE)      # the table is per 512 x 512 tile
     per_gpu = tiles_per_s / world
     roof["whole_step"] = {"algorithmic_GBps": step_bytes * per_gpu / 1e9, "hbm_frac": step_bytes * per_gpu / 1e9 / HBM_PEAK_GBPS,
                           "algorithmic_TFLOPs": step_flop * per_gpu / 1e12, "fp32_mfma_frac": step_flop * per_gpu / 1e12 / FP32_MFMA_PEAK_TFLOPS,
@@ -359,6 +375,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="dn_train", choices=["dn_train", "sr_train", "dn_fwd", "sr_fwd"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 32 at every N; sr_fwd: 16)")
+    ap.add_argument("--tile", type=int, default=TILE,
+                    help="LR tile side in pixels (default 512 = BASELINE's metric).  416 = the reference's own operating point "
+                         "(res/baseline_config.toml:13 lr_res, 832 HR); any other value is NOT the headline: the metric names the size, "
+                         "no cpu_baseline, no PMC traffic")
     ap.add_argument("--math", default=os.environ.get("XSD_MATH", DEFAULT_MATH), choices=sorted(MATHS),
                     help="MFMA math mode of the conv kernels (include/xsd.h: xsd_set_math); the headline must be fp32-class")
     ap.add_argument("--input-pipeline", action="store_true",
@@ -426,6 +446,11 @@ def main():
     train = mode == "train"
     B = args.batch or (16 if args.workload == "sr_fwd" else 32)
     scale = 2 if kind == "sr" else 1
+    T = args.tile
+    if T < 16 or T > 2048:
+        raise SystemExit("--tile must be in [16, 2048]")
+    if args.input_pipeline and T < 411:
+        raise SystemExit("--input-pipeline pads 411 x 403 count tiles: --tile must be >= 411")
 
     torch.manual_seed(0)  # same seeded default init on every rank (DP replicas start identical)
     NF = args.filters
@@ -433,10 +458,10 @@ def main():
     # synthetic data: global batch generated from one seed, each rank takes its shard (DistributedSampler analogue)
     gx = torch.Generator().manual_seed(0)
     gt = torch.Generator().manual_seed(1)
-    x = torch.rand((B * world, 1, TILE, TILE), generator=gx)[rank * B:(rank + 1) * B].contiguous().to(dev)
+    x = torch.rand((B * world, 1, T, T), generator=gx)[rank * B:(rank + 1) * B].contiguous().to(dev)
     tgt = None
     if train:
-        tgt = torch.rand((B * world, 1, TILE * scale, TILE * scale), generator=gt)[rank * B:(rank + 1) * B].contiguous().to(dev)
+        tgt = torch.rand((B * world, 1, T * scale, T * scale), generator=gt)[rank * B:(rank + 1) * B].contiguous().to(dev)
 
     model.set_math(args.math)
     loss_fn = None
@@ -464,7 +489,7 @@ def main():
 
     def step():
         if args.input_pipeline:
-            xin = compose_input(counts, None, None, mask, TILE, 0.0022336, "sqrt")  # 411x403 -> centred pad to 512
+            xin = compose_input(counts, None, None, mask, T, 0.0022336, "sqrt")  # 411x403 -> centred pad to the tile (512; 416 = data/tools.py:103-126)
             if train:
                 return trainer.train_step(xin, tgt)
             with torch.no_grad():
@@ -507,7 +532,7 @@ def main():
         comm_ms = trainer.comm_events_end() / nsteps if train else None
         prof = None
         if profile:
-            prof = {0: eng.profile_read(0), 1: eng.profile_read(1)}
+            prof = {k: eng.profile_read(k) for k in range(len(PROFILE_CLASSES))}
             eng.profile_enable(False)
         return dt, mine, prof, comm_ms
 
@@ -516,12 +541,25 @@ def main():
     pwatch = PowerWatch(pci=[my_pci] if my_pci else None)
     dt, my_dt, prof, comm_ms = timed(args.warmup, args.steps, not args.no_profile, pwatch)
     power = pwatch.summary()
+    # The headline's timed region carries the per-launch HIP events the roofline block is computed from (two hipEventRecord per
+    # MFMA-kernel launch: ~0.2 % of a batch-32 step, ~10 % of a batch-1 step).  The same K steps once more WITHOUT them, reported
+    # beside the headline as `unprofiled` -- what a user's step costs
+    dt_plain = None
+    if not args.no_profile:
+        dt_plain, _, _, _ = timed(0, args.steps, False)
 
     # the rate the matrix pipes of THIS device sustain on the conv's bare MFMA stream, measured now, in this process
     # (include/xsd.h: xsd_probe_mfma_stream): the roof the package power cap leaves of the nominal 2.5 PFLOP/s
     sustained = None
     if args.math in MATH_PRODUCTS and not args.no_sustained:
-        sustained = eng.probe_mfma_stream("f16" if args.math == "f16x3" else "bf16", args.sustained_seconds)
+        fmt = "f16" if args.math == "f16x3" else "bf16"
+        if dp and world > ndev:      # a rehearsal with ranks SHARING a device: one rank at a time, or per_rank.sustained_mfma_tflops is a contended figure that reads as device spread
+            for r in range(world):
+                if r == rank:
+                    sustained = eng.probe_mfma_stream(fmt, args.sustained_seconds)
+                dist.barrier()
+        else:
+            sustained = eng.probe_mfma_stream(fmt, args.sustained_seconds)
 
     per_rank = None
     if dp:      # what a < N x curve is made of: every rank's own step time, device clock and watts, exposed exchange wait
@@ -550,6 +588,13 @@ def main():
     psnr_delta = None
     if rank == 0 and NF == 32 and not args.no_psnr:
         psnr_delta = psnr_delta_vs_reference(kind, args.math, dev)
+        # north_star names the XMM-SuperRes PSNR: every line carries BOTH generators' figures (psnr.sr_delta_db, psnr.dn_delta_db);
+        # the top-level psnr_delta_db stays the timed workload's kind
+        other = "sr" if kind == "dn" else "dn"
+        o = psnr_delta_vs_reference(other, args.math, dev)
+        psnr_delta["psnr"][kind + "_delta_db"] = psnr_delta["psnr_delta_db"]
+        psnr_delta["psnr"][other + "_delta_db"] = o["psnr_delta_db"]
+        psnr_delta["psnr"][other] = o["psnr"]
 
     # ---- extra leg (same process, same inputs): another math mode over the same --steps/--warmup, labelled; never the headline
     extra = None
@@ -572,31 +617,34 @@ def main():
             extra["power"]["joules_per_tile"] = round(extra["power"]["avg_w"] * (dte / args.steps) / B, 3)
         if profe is not None and profe[0]["launches"] > 0:
             xs = eng.probe_mfma_stream("f16" if xm == "f16x3" else "bf16", args.sustained_seconds) if (xm in MATH_PRODUCTS and not args.no_sustained) else None
-            extra["roofline"] = roofline_block(xm, profe, B, kind, train, world, B * world * args.steps / dte, NF == 32, xs)
+            extra["roofline"] = roofline_block(xm, profe, B, kind, train, world, B * world * args.steps / dte, NF == 32, xs, T)
         model.set_math(args.math)
 
     if rank == 0:
         tiles = B * world * args.steps
         dtype, kname = MATHS[args.math]
         out = {
-            "metric": "XMM 512x512 tiles/sec (train step)" if train else "XMM 512x512 tiles/sec (forward)",
+            "metric": f"XMM {T}x{T} tiles/sec (train step)" if train else f"XMM {T}x{T} tiles/sec (forward)",
             "value": tiles / dt, "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": {"dn_train": "XMM-DeNoise train step (%s + Adam), fwd+bwd HIP kernels" % ("L1" if args.loss == "l1" else "0.5 PSNR + 0.5 MS-SSIM"),
                                     "sr_train": "XMM-SuperRes 2x train step (%s + Adam)" % ("L1" if args.loss == "l1" else "0.5 PSNR + 0.5 MS-SSIM"),
                                     "dn_fwd": "XMM-DeNoise forward", "sr_fwd": "XMM-SuperRes 2x generator forward"}[args.workload],
-                       "tile": f"1x{TILE}x{TILE}", "per_gpu_batch": B, "global_batch": B * world,
+                       "tile": f"1x{T}x{T}", "per_gpu_batch": B, "global_batch": B * world,
                        "layers": "RRDB generator, 32 filters x 4 blocks (res/configs/models.toml)" if NF == 32 else f"RRDB generator, {NF} filters x 4 blocks (NOT the BASELINE width)",
                        "math": args.math,
                        "parallelism": f"dp{world}", "dist_backend": backend if dp else None},
         }
+        if dt_plain is not None:
+            out["unprofiled"] = {"value": tiles / dt_plain, "ms_per_step": 1e3 * dt_plain / args.steps,
+                                 "note": "the same K steps again without the per-launch HIP events of the roofline block"}
         if NF % 32:
             out["config"]["runs_zero_padded_to_filters"] = (NF + 31) // 32 * 32      # the kernels' flop / byte counts below are those of the padded width
         if replicas_identical is not None:
             out["replicas_identical"] = replicas_identical
         if prof is not None and prof[0]["launches"] > 0:
-            out["roofline"] = roofline_block(args.math, prof, B, kind, train, world, tiles / dt, NF == 32, sustained)
+            out["roofline"] = roofline_block(args.math, prof, B, kind, train, world, tiles / dt, NF == 32, sustained, T)
         if power is not None:
             # the step runs at the package cap, so the rate IS watts / joules per tile: the figure a kernel change has to move
             power["joules_per_tile"] = round(power["avg_w"] * (dt / args.steps) / B, 3)
@@ -609,7 +657,7 @@ def main():
             out.update(psnr_delta)
         if extra is not None:
             out["extra"] = extra
-        if world == 1 and not args.no_cpu_baseline and NF == 32:
+        if world == 1 and not args.no_cpu_baseline and NF == 32 and T == TILE:
             out["cpu_baseline"] = cpu_baseline(kind, train)
         print(json.dumps(out), flush=True)
     if dp:

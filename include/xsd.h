@@ -76,13 +76,16 @@ int64_t xsd_param_count(const xsd_engine* e);
  * (Modes 1 and 2 -- two-term bf16 splits with 16-bit significands -- existed in rounds 1-2 and were removed.)
  * Default: 4 (f16x3), or the environment variable XSD_MATH ("fp32" | "bf16x6" | "f16x3"; anything else fails xsd_create).
  * Changing it invalidates the packed weights and the plan.
- * Other environment variables the production library reads (each once per process; results are identical to rounding either way):
+ * XSD_MATH is the ONLY environment variable the production library (lib/libxsd_hip.so) reads.  Since round 6 the A/B switches and
+ * test hooks below are compiled only into the test-hooks variant (make -C csrc hooks -> lib/libxsd_hip_hooks.so = the product's
+ * objects with xsd_engine.hip built -DXSD_TEST_HOOKS; selected with XSD_LIB=<path>, as the diagnostic variant is) -- a shipped
+ * library does not replan on an environment variable (tests/test_hip_network.py holds the product to that):
  *   XSD_WGRAD_BLOCK=0   the weight gradients of a dense block as one launch per G (five launches) instead of ONE pair-list launch
  *                       over its 15 (X, G) pairs (default 1; A/B switch, tools/ab_env.sh; tests hold the two forms to 2e-6);
  *   XSD_WGRAD_TAIL=0    no extra part on the CUs the block launch's 8 m x 15 workgroups leave (default 1; MI355X: a 17th part);
- *   XSD_TEST_NCU=n      TEST HOOK: plan the block launch as if the device had n compute units (n < 120: one launch per G);
- *   XSD_TEST_AMAX_CAP=n TEST HOOK: initial capacity of the max-|x| slot array (default 65536 floats), so that a small net
- *                       exercises the grow / copy / rebuild path a 256-filter x 64-block net would take.
+ *   XSD_TEST_NCU=n      plan the block launch as if the device had n compute units (n < 120: one launch per G);
+ *   XSD_TEST_AMAX_CAP=n initial capacity of the max-|x| slot array (default 65536 floats), so that a small net exercises the
+ *                       grow / copy / rebuild path a 256-filter x 64-block net would take.
  * Modes 3 and 4 address a plane's batch slice with 32-bit byte offsets: images of 2^24 or more output pixels are rejected
  * by xsd_forward (mode 0 takes them). */
 int xsd_set_math(xsd_engine* e, int mode);
@@ -174,8 +177,12 @@ int xsd_normalize(const float* dev_in, float* dev_out, int64_t n, float max_val,
 int xsd_image_upsample(const float* dev_in, float* dev_out, int N, int H, int W, int scale, void* stream);
 
 /* ---- measurement / test hooks ------------------------------------------------------------------------------- */
-/* Per-kernel-class HIP-event timing of the MFMA kernels launched by this engine (bench.py roofline block).
- * class 0 = conv3x3_mfma (forward + input-gradient), 1 = wgrad_mfma.  enable resets the counters. */
+/* Per-kernel-class HIP-event timing of the kernels launched by this engine (bench.py roofline block), with each launch's
+ * ALGORITHMIC flop and bytes (SURVEY.md 8d counting rule: every operand once).  MFMA-bound classes: 0 = conv (forward +
+ * input-gradient), 1 = weight gradient.  HBM-bound classes (round 6): 2 = edge_expand (conv_first forward, conv_last input-gradient:
+ * 1 -> 32 channels), 3 = edge_reduce (conv_last forward + skip + clamp, conv_first input-gradient: 32 -> 1), 4 = edge_wgrad
+ * (weight gradients of the two edge layers), 5 = xsd_l1_loss, 6 = xsd_adam_step, 7 = clamp backward, 8 = max-|x| sweeps of
+ * planes no producer reported (f16x3).  enable resets the counters; unknown classes read as zero launches. */
 int xsd_profile_enable(xsd_engine* e, int enable);
 int xsd_profile_read(xsd_engine* e, int klass, double* total_ms, int64_t* launches, double* total_flop, double* total_bytes);
 

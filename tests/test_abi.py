@@ -165,3 +165,28 @@ def test_library_holds_only_the_adopted_conv_kernel_instances():
     syms = subprocess.run(["nm", "-C", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     built = {int(m) for m in re.findall(r"__device_stub__conv3x3_h2x_kind_kernel<(\d+)>", syms)}
     assert built == adopted, (built, adopted)
+
+
+def test_product_library_reads_no_test_hook_from_the_environment():
+    """Round 6: XSD_WGRAD_BLOCK / XSD_WGRAD_TAIL / XSD_TEST_NCU / XSD_TEST_AMAX_CAP live in the test-hooks variant only
+    (make -C csrc hooks; include/xsd.h).  The product library's binary does not even hold their names; the hooks variant holds
+    all four and exports the same C ABI."""
+    import ctypes
+    from xmm_superres_denoise.engine import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prod = os.path.join(root, "xmm-superres-denoise_amd", "lib", "libxsd_hip.so")
+    hooks = os.path.join(root, "xmm-superres-denoise_amd", "lib", "libxsd_hip_hooks.so")
+    names = (b"XSD_WGRAD_BLOCK", b"XSD_WGRAD_TAIL", b"XSD_TEST_NCU", b"XSD_TEST_AMAX_CAP")
+    blob = open(prod, "rb").read()
+    assert b"XSD_MATH" in blob
+    for n in names:
+        assert n not in blob, n
+    assert os.path.exists(hooks), "make -C xmm-superres-denoise_amd/csrc hooks (__graft_entry__.build() does)"
+    hb = open(hooks, "rb").read()
+    for n in names:
+        assert n in hb, n
+    L = ctypes.CDLL(hooks)
+    for s in _lib.ABI_SYMBOLS:
+        assert hasattr(L, s), s
+    L.xsd_version.restype = ctypes.c_char_p
+    assert b"test-hooks" in L.xsd_version()

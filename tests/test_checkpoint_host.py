@@ -41,7 +41,24 @@ def test_checkpoint_with_a_non_tensor_payload_is_refused(tmp_path):
     sd = {"model." + k: torch.zeros_like(v) for k, v in before.items()}
     p = os.path.join(tmp_path, "third_party.ckpt")
     torch.save({"state_dict": sd, "callbacks": _Payload()}, p)
-    with pytest.raises(pickle.UnpicklingError):
+    # refused, with a message that says what is accepted and how to reduce the file (round 6; the cause is torch's UnpicklingError)
+    with pytest.raises(RuntimeError, match="weights_only=True") as ei:
         load_checkpoint(p, m)
+    assert isinstance(ei.value.__cause__, pickle.UnpicklingError) and "state_dict" in str(ei.value) and "hyper_parameters" in str(ei.value)
     for k, v in before.items():      # refused before anything was applied
         assert torch.equal(v, m.model.state_dict()[k]), k
+
+
+def test_bare_state_dict_without_the_lightning_prefix_loads(tmp_path):
+    from xmm_superres_denoise.train import load_checkpoint
+    torch.manual_seed(4)
+    a, b = _tiny_model(), _tiny_model()
+    p = os.path.join(tmp_path, "bare.ckpt")
+    torch.save({"state_dict": {k: v.detach().clone() for k, v in a.model.state_dict().items()}}, p)
+    load_checkpoint(p, b)
+    for k, v in a.model.state_dict().items():
+        assert torch.equal(v, b.model.state_dict()[k]), k
+    q = os.path.join(tmp_path, "nothing.ckpt")
+    torch.save({"weights": 1}, q)
+    with pytest.raises(RuntimeError, match="no `state_dict`"):
+        load_checkpoint(q, b)

@@ -72,3 +72,104 @@ def test_ragged_and_tiny_shapes():
         with torch.no_grad():
             y = m(torch.from_numpy(x).cuda()).cpu().numpy()
         assert y.shape == yo.shape and np.abs(y - yo).max() < 1e-5, shape
+
+
+def test_batch_that_cannot_fit_fails_cleanly_and_memory_efficient_trains_it():
+    """rrdb_blocks.py:39-47: the reference's way out of a batch whose activations do not fit is `memory_efficient` (recompute).
+    A training step keeps 62 planes of 128 B per pixel = 2.1 GB per 512 x 512 tile: 160 tiles = 333 GiB, more than the device has.
+    The engine must (a) refuse it with XSD_ERR_NOMEM and a message that names memory_efficient, (b) stay usable: a batch that fits
+    then gives results bit-equal to a fresh engine's, (c) train the SAME batch with memory_efficient=True."""
+    import numpy as np
+    import gen_common as gc
+    from util_hip import build_module
+    from xmm_superres_denoise.engine import XsdError
+    from xmm_superres_denoise.models import GeneratorRRDB_DN
+    from xmm_superres_denoise.parallel import DataParallelTrainer
+    total = torch.cuda.get_device_properties(0).total_memory
+    B, T = 160, 512
+    assert B * 62 * 128 * T * T > total, "this device would hold the batch: raise B"
+    state = gc.make_state("dn", 32, 4, 4242)
+    m = build_module("dn", 4, 1, state)
+    g = torch.Generator().manual_seed(5)
+    xs = torch.rand((2, 1, 96, 64), generator=g).cuda()
+    ts = torch.rand((2, 1, 96, 64), generator=g).cuda()
+    tr = DataParallelTrainer(m, lr=1e-4)
+    x = torch.rand((B, 1, T, T), generator=g).cuda()
+    t = torch.rand((B, 1, T, T), generator=g).cuda()
+    before = tr.flat.clone()
+    with pytest.raises(XsdError, match="memory_efficient") as ei:
+        tr.train_step(x, t)
+    assert "GiB" in str(ei.value) and "does not fit" in str(ei.value)
+    assert torch.equal(tr.flat, before) and tr.step_count == 0           # nothing was updated by the refused step
+    # (b) the engine that refused goes on: same small step as a fresh module, bit for bit (loss, every gradient, updated weights)
+    l1 = tr.train_step(xs, ts)
+    m2 = build_module("dn", 4, 1, state)
+    tr2 = DataParallelTrainer(m2, lr=1e-4)
+    l2 = tr2.train_step(xs, ts)
+    torch.cuda.synchronize()
+    assert torch.equal(l1, l2) and torch.equal(tr.grads, tr2.grads) and torch.equal(tr.flat, tr2.flat)
+    # a forward-only batch of the same size fits (9 recycled planes) and still works after the refusal
+    del tr, tr2, m2
+    with torch.no_grad():
+        y = m(x[:64])
+    assert y.shape == (64, 1, T, T) and bool(torch.isfinite(y).all())
+    del y, m
+    torch.cuda.empty_cache()
+    # (c) the same 160-tile batch trains with memory_efficient=True (8 tiles at a time are recomputed and back-propagated)
+    mme = GeneratorRRDB_DN(1, 1, 32, 4, memory_efficient=True)
+    mme.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
+    mme = mme.cuda()
+    trm = DataParallelTrainer(mme, lr=1e-4)
+    w0 = trm.flat.clone()
+    la = float(trm.train_step(x, t))
+    lb = float(trm.train_step(x, t))
+    torch.cuda.synchronize()
+    assert np.isfinite(la) and np.isfinite(lb) and bool(torch.isfinite(trm.grads).all())
+    assert not torch.equal(trm.flat, w0) and lb < la                   # two Adam steps on a fixed batch: the loss falls
+    # ... and its gradient is the full-batch gradient: against 16 of the tiles kept whole on a second engine (chunks are independent)
+    m16 = build_module("dn", 4, 1, state)
+    tr16 = DataParallelTrainer(m16, lr=1e-4)
+    trm2 = DataParallelTrainer(GeneratorRRDB_DN(1, 1, 32, 4, memory_efficient=True).cuda(), lr=1e-4)
+    trm2.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
+    trm2.flat = trm2.model.flat_parameters()
+    tr16.train_step(x[:16].contiguous(), t[:16].contiguous())
+    trm2.train_step(x[:16].contiguous(), t[:16].contiguous())
+    torch.cuda.synchronize()
+    scale = float(tr16.grads.abs().max())
+    assert float((tr16.grads - trm2.grads).abs().max()) <= 2e-6 * scale + 1e-12
+
+
+@pytest.mark.parametrize("bad", ["nan", "inf", "-inf"])
+def test_non_finite_input_propagates_like_the_reference(bad):
+    """One non-finite input pixel: torch propagates it through every conv it reaches (a 3 x 3 conv spreads it by one pixel, 0 * nan = nan,
+    inf - inf = nan), LeakyReLU and the residual sums keep it, torch.clamp keeps nan and sends +-inf to the bounds
+    (generator_rrdb.py:130-137, models/model.py:48-49).  The set of non-finite OUTPUT pixels of the engine equals the oracle's in all
+    three math modes, the finite ones stay within the usual tolerance, and the tile next to it in the batch is untouched.
+    (Until round 6 the output clamp was fminf(fmaxf()), which returns the non-nan operand: a nan pixel came out as 0.)"""
+    import numpy as np
+    import gen_common as gc
+    from oracle import oracle
+    from util_hip import build_module
+    state = gc.make_state("dn", 32, 1, 977)
+    m = build_module("dn", 1, 1, state)
+    x = gc.make_input((2, 1, 80, 72), 978)
+    x[0, 0, 40, 30] = {"nan": np.nan, "inf": np.inf, "-inf": -np.inf}[bad]
+    with np.errstate(invalid="ignore", over="ignore"):
+        yo = oracle.forward("dn", 32, 1, oracle.flatten_state(state), x)
+    bad_o = ~np.isfinite(yo)
+    # 18 convs between input and output (conv_first, 15 in the dense blocks, trunk_conv, conv_last): everything within 18 pixels of (40, 30) in tile 0, nothing in tile 1
+    assert bad_o[1].sum() == 0 and bad_o[0].sum() == 37 * 37, bad_o.sum()
+    for mode in ("f16x3", "bf16x6", "fp32"):
+        m.set_math(mode)
+        with torch.no_grad():
+            y = m(torch.from_numpy(x).cuda()).cpu().numpy()
+        bad_e = ~np.isfinite(y)
+        assert np.array_equal(bad_e, bad_o), (mode, int(bad_e.sum()), int(bad_o.sum()), int((bad_e ^ bad_o).sum()))
+        assert np.isnan(y[bad_e]).all() and np.isnan(yo[bad_o]).all()            # clamp leaves no inf behind, in either
+        ok = ~bad_o
+        assert np.abs(y[ok] - yo[ok]).max() < 2e-5, (mode, float(np.abs(y[ok] - yo[ok]).max()))
+        # and the engine is not poisoned: the same module on a clean batch right afterwards
+        xc = gc.make_input((2, 1, 80, 72), 979)
+        with torch.no_grad():
+            yc = m(torch.from_numpy(xc).cuda()).cpu().numpy()
+        assert np.isfinite(yc).all() and np.abs(yc - oracle.forward("dn", 32, 1, oracle.flatten_state(state), xc)).max() < 1e-5, mode

@@ -496,12 +496,17 @@ def test_block_weight_gradient_launch_equals_one_launch_per_g(tmp_path, math):
     # variants (include/xsd.h): the default (MI355X: 16 parts + a 17th on the spare CUs), one launch per G, no tail part, and the
     # plans of devices with other CU counts (XSD_TEST_NCU: 128 CUs -> 8 parts, no tail; 140 -> 8 parts + tail; 100 -> fewer than
     # one part per XCD: falls back to one launch per G).  Every cut of the tiles into partial sums must give the same gradient.
-    variants = {"default": {}, "per_g": {"XSD_WGRAD_BLOCK": "0"}, "no_tail": {"XSD_WGRAD_TAIL": "0"},
-                "ncu128": {"XSD_TEST_NCU": "128"}, "ncu140": {"XSD_TEST_NCU": "140"}, "ncu100": {"XSD_TEST_NCU": "100"}}
+    # Round 6: only the test-hooks variant of the library reads these variables (make -C csrc hooks -> lib/libxsd_hip_hooks.so, selected
+    # with XSD_LIB; include/xsd.h); the product library ignores them -- "product" runs it with every switch set and must equal "default".
+    hooks = os.path.join(root, "xmm-superres-denoise_amd", "lib", "libxsd_hip_hooks.so")
+    assert os.path.exists(hooks), "build the hooks variant: make -C xmm-superres-denoise_amd/csrc hooks (__graft_entry__.build() does)"
+    variants = {"default": {"XSD_LIB": hooks}, "per_g": {"XSD_LIB": hooks, "XSD_WGRAD_BLOCK": "0"}, "no_tail": {"XSD_LIB": hooks, "XSD_WGRAD_TAIL": "0"},
+                "ncu128": {"XSD_LIB": hooks, "XSD_TEST_NCU": "128"}, "ncu140": {"XSD_LIB": hooks, "XSD_TEST_NCU": "140"}, "ncu100": {"XSD_LIB": hooks, "XSD_TEST_NCU": "100"},
+                "product": {"XSD_WGRAD_BLOCK": "0", "XSD_WGRAD_TAIL": "0", "XSD_TEST_NCU": "100"}}
     outs = {}
     for name, extra in variants.items():
         out = str(tmp_path / f"g_{name}.npz")
-        env = {k: v for k, v in os.environ.items() if k not in ("XSD_WGRAD_BLOCK", "XSD_WGRAD_TAIL", "XSD_TEST_NCU")}
+        env = {k: v for k, v in os.environ.items() if k not in ("XSD_WGRAD_BLOCK", "XSD_WGRAD_TAIL", "XSD_TEST_NCU", "XSD_LIB")}
         env.update(extra)
         p = subprocess.run([sys.executable, "-c", code, root, out, math], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         assert p.returncode == 0, (name, p.stdout.decode(errors="replace")[-3000:])
@@ -519,6 +524,8 @@ def test_block_weight_gradient_launch_equals_one_launch_per_g(tmp_path, math):
     assert any(not np.array_equal(outs["default"][k], b[k]) for k in b.files)
     assert any(not np.array_equal(outs["no_tail"][k], outs["default"][k]) for k in b.files)
     assert any(not np.array_equal(outs["ncu128"][k], outs["default"][k]) for k in b.files)
+    for k in b.files:      # the product library does not replan on an environment variable
+        assert np.array_equal(outs["product"][k], outs["default"][k]), k
 
 
 def test_max_abs_slot_array_grows_without_changing_results(tmp_path):
@@ -543,12 +550,15 @@ def test_max_abs_slot_array_grows_without_changing_results(tmp_path):
         "g = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()}\n"
         "g['dx'] = xg.grad.detach().cpu().numpy(); g['y0'] = y0; g['y'] = y.detach().cpu().numpy()\n"
         "np.savez(sys.argv[2], **g)\n")
+    hooks = os.path.join(root, "xmm-superres-denoise_amd", "lib", "libxsd_hip_hooks.so")      # the only build that reads the variable (round 6)
+    assert os.path.exists(hooks), "build the hooks variant: make -C xmm-superres-denoise_amd/csrc hooks"
     outs = []
     for cap in (None, "128"):
         out = str(tmp_path / f"cap_{cap}.npz")
-        env = {k: v for k, v in os.environ.items() if k != "XSD_TEST_AMAX_CAP"}
+        env = {k: v for k, v in os.environ.items() if k not in ("XSD_TEST_AMAX_CAP", "XSD_LIB")}
         if cap:
             env["XSD_TEST_AMAX_CAP"] = cap
+            env["XSD_LIB"] = hooks
         p = subprocess.run([sys.executable, "-c", code, root, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
         outs.append(np.load(out))

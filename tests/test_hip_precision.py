@@ -185,7 +185,7 @@ def _per_tensor(flat, ref, shapes):
 
 
 def _net_errors(size, blocks, seed, with_grad, batch=1, flip_aware=False, kind="dn", tight_w=2e-4, strict_w=1e-3, with_torch32=True, dx_loose=5e-2,
-                dx_flip_frac=0.1):
+                dx_flip_frac=0.1, dx_l2_bar=2.5e-2):
     """DN (or SR 2x) generator, `blocks` RRDB blocks, `batch` tiles of size x size, seeded weights and input; gradient of the linear
     functional <dy, y> (no loss discontinuity).  Returns {mode: {y, g, dx, t_rms, t_max}} relative to float64 torch, with
     torch's own fp32 path as one of the modes.  flip_aware: also hold every mode's every gradient tensor and dL/dx to the
@@ -266,7 +266,7 @@ def _net_errors(size, blocks, seed, with_grad, batch=1, flip_aware=False, kind="
             e_dx = np.abs(dx.astype(np.float64) - dx64).reshape(-1, size) / np.abs(dx64).max()
             print(f"    {math}: dL/dx rows over 4e-4: {100 * float((e_dx.max(axis=1) > 4e-4).mean()):.1f} %, worst pixel {e_dx.max():.2e}, "
                   f"relative L2 {np.linalg.norm(dx - dx64) / np.linalg.norm(dx64):.2e}", flush=True)
-            assert_grad_close(dx.reshape(-1, size), dx64.reshape(-1, size), "dx", tight=4e-4, loose=dx_loose, max_flip_frac=dx_flip_frac, l2_bar=2.5e-2)
+            assert_grad_close(dx.reshape(-1, size), dx64.reshape(-1, size), "dx", tight=4e-4, loose=dx_loose, max_flip_frac=dx_flip_frac, l2_bar=dx_l2_bar)
             off = 0
             for name, shp in shapes.items():
                 k = int(np.prod(shp))
@@ -385,10 +385,11 @@ def test_sr_backward_every_tensor_at_the_configs3_share_vs_float64():
     dL/dx bars at this size: worst pixel 1e-1 of max |dL/dx| and 20 % of the image rows above 4e-4 (256 x 256: 5e-2 and 10 %).
     Measured: the EXACT-fp32 mode -- an fp32 fma chain on kernels that share no code with the split modes -- has 10.6 % of the rows
     over 4e-4 and a worst pixel of 5.6e-2; bf16x6 4.1 % / 2.3e-2, f16x3 5.9 % / 5.6e-2; relative L2 4 - 6e-4 for all three (bar:
-    2.5e-2).  That is flip noise (64 x the LeakyReLU' decisions of the small case: the extreme of the same distribution), not a
+    3e-3 since round 6, five times the measured value: a structural edge error of ~1 % L2 confined to a few rows -- which the two
+    row-wise allowances above would let through -- fails it).  That is flip noise (64 x the LeakyReLU' decisions of the small case: the extreme of the same distribution), not a
     tile-edge error: a structural error would be percents of L2 and show in the row-wise check of every parameter gradient."""
     errs, frac = _net_errors(512, 4, 7901, with_grad=True, batch=16, flip_aware=True, kind="sr", tight_w=2e-3, strict_w=5e-3, with_torch32=False,
-                             dx_loose=1e-1, dx_flip_frac=0.2)
+                             dx_loose=1e-1, dx_flip_frac=0.2, dx_l2_bar=3e-3)
     _table(f"SR 2x, 16 tiles of 512^2 -> 1024^2 x 4 blocks, seed 7901: errors vs float64 ({100 * frac:.0f}% of output pixels unclamped):", errs)
     for m in SPLITS:
         assert errs[m]["y"] <= errs["fp32"]["y"], m

@@ -1,4 +1,6 @@
 # same-library, same-device A/B of an engine switch read from the environment: bash tools/ab_env.sh VAR   (alternates VAR=0 / VAR=1)
+# (round 6: only the test-hooks variant of the library reads these switches -- make -C xmm-superres-denoise_amd/csrc hooks)
+export XSD_LIB=${XSD_LIB:-$GRAFT_REPO_ROOT/xmm-superres-denoise_amd/lib/libxsd_hip_hooks.so}
 V=$1
 for R in 0 1 0 1; do
   export $V=$R

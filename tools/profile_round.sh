@@ -27,6 +27,6 @@ python3 bench.py --loss paper --steps 4 --warmup 1 --no-cpu-baseline --no-extra 
 python3 bench.py --input-pipeline --batch 16 --steps 4 --warmup 1 --no-cpu-baseline --no-extra --no-sustained --no-psnr > $O/${TAG}_bench_dn_train_input_pipeline_b16.json 2>/dev/null || exit 1
 python3 bench.py --batch 16 --steps 6 --warmup 2 --no-cpu-baseline --no-extra --no-sustained --no-psnr > $O/${TAG}_bench_dn_train_b16.json 2>/dev/null || exit 1
 # the RCCL code path on the one GPU: a one-rank nccl process group with the reduce path forced on (parallel.collectives_on)
-XSD_FORCE_DP=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 python3 bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline --no-extra --no-sustained --no-psnr > $O/${TAG}_bench_dp1_rccl_one_gpu.json 2> $O/dp1_rccl.err || exit 1
-XSD_DIST_BACKEND=gloo python3 bench.py --gpus 2 --batch 8 --steps 3 --warmup 1 --no-extra > $O/${TAG}_bench_dp2_gloo_one_gpu.json 2> $O/dp2.err || exit 1
+XSD_FORCE_DP=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 python3 bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline --no-extra --no-sustained --no-psnr 2> $O/dp1_rccl.err | grep '^{' > $O/${TAG}_bench_dp1_rccl_one_gpu.json || exit 1      # (RCCL / gloo print banners on stdout: the .json holds the line only)
+XSD_DIST_BACKEND=gloo python3 bench.py --gpus 2 --batch 8 --steps 3 --warmup 1 --no-extra 2> $O/dp2.err | grep '^{' > $O/${TAG}_bench_dp2_gloo_one_gpu.json || exit 1
 echo all done

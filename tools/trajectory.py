@@ -22,23 +22,27 @@ backward parity says nothing about how a math mode's rounding accumulates over s
 What the first runs showed (profiles/r05_trajectory.txt): this optimisation is chaotic at the 0.02 - 0.35 dB level.  Every
 fp32-class run -- torch's own two float32 paths, the exact-fp32 MFMA mode, the exact bf16x6 split, f16x3 -- and every
 ulp-perturbed float64 run ends 0.02 - 0.3 dB from the float64 run at step 200 and up to 0.35 dB around step 100, where the
-loss curve has a bump; the absolute 0.01 dB the round-4 review asked for at step 200 is met by NO fp32 arithmetic, torch's
-included -- float64 itself misses it by 0.01 - 0.49 dB when its start weights move by one fp32 ulp.  tools/trajectory_scan.py
-(profiles/r05_trajectory_scan.txt) ran 24 other data sets (tile 64 - 128, batch 4 / 16, two seeds, two noise levels): the three
-engine modes stay within 5e-3 dB of each other up to step 50 on every one and are 0.02 - 1.6 dB apart by step 200 on every one.
-The chaos belongs to the optimisation (random init, Adam at 1e-4 on an L1 loss), not to any arithmetic or data choice.
-The bar (tests/test_hip_trajectory.py asserts it), for every engine mode, at steps 10 / 25 / 50 / 100 / 200:
-  * step 10 (the divergence is still at rounding level): |PSNR - PSNR_f64| <= 1e-4 dB and |loss - loss_f64| <= 2e-6 outright.
-    Every fp32-class arithmetic sits at ~4e-6 dB / 1.5e-7 there (torch float32, the three engine modes); conv operands rounded to
-    16 significant bits are at 1e-3 dB / 3e-5, to 20 bits at 1e-4 dB (tools/trajectory_sigbits_probe.py): the run carries that
-    16-bit arithmetic as a NEGATIVE CONTROL leg, which must fail this bar.  (The review's 0.01 dB would not catch it.)
-  * later checkpoints: |loss - loss_f64| and |PSNR - PSNR_f64| <= max(2 x the largest such distance among the yard-sticks (torch
-    float32 on the host cores and on the GPU, the ulp-perturbed float64 runs), an allowance of 0.01 dB / 1e-4 up to step 50 and
-    1 dB / 5e-3 beyond).  Past the onset (steps 50 - 60: the distance grows 20 x per 10 steps) a distance is one draw from a wide
-    distribution, and "2 x the largest of six yard-sticks" alone would fail a legitimate run about every tenth time.
-`report()` also lists which runs meet 0.01 dB at the last checkpoint (for the record; the yard-sticks' own figures beside it).
+loss curve has a bump; float64 itself misses 0.01 dB by 0.01 - 0.49 dB when its start weights move by one fp32 ulp.
+tools/trajectory_scan.py (profiles/r05_trajectory_scan.txt) ran 24 other data sets: the three engine modes stay within 5e-3 dB
+of each other up to step 50 on every one and are 0.02 - 1.6 dB apart by step 200 on every one.  The chaos belongs to the
+optimisation (random init, Adam at 1e-4 on an L1 loss), not to any arithmetic or data choice.  Consequence (round 6): PAST STEP
+~50 A SINGLE RUN CARRIES NO INFORMATION ABOUT THE ARITHMETIC -- round 5's per-run allowances there (0.01 dB to step 50, 1 dB
+beyond) were passed by the 16-bit negative control at every checkpoint and are gone.  What is held instead:
 
-Run on the GPU box: `python tools/trajectory.py [--steps 200] [--size 96] [--out profiles/r05_trajectory.txt]`.
+  (1) step 10, single run from the unperturbed start (the divergence is still at rounding level): |PSNR - PSNR_f64| <= 1e-4 dB and
+      |loss - loss_f64| <= 2e-6 outright, for every engine mode.  Every fp32-class arithmetic sits at ~4e-6 dB / 1.5e-7 there;
+      conv operands rounded to 16 significant bits are at 1e-3 dB / 3e-5 (tools/trajectory_sigbits_probe.py): the run carries
+      that arithmetic as a NEGATIVE CONTROL leg (`control_16bit`), which must FAIL this bar (main() exits non-zero if it passes).
+  (2) step `steps` (200), an ENSEMBLE per arithmetic: K members whose start weights are moved by at most one fp32 ulp each
+      (member 0: the unperturbed start; the same K starts for every arithmetic), for torch float64, the engine's f16x3 / bf16x6 /
+      fp32 and the control.  The step-200 loss and the step-200 PSNR (mean of the two held-out tiles) are then two samples per
+      arithmetic of what the chaotic trajectory does with a rounding-sized perturbation, and an arithmetic is held to the
+      DISTRIBUTION float64 produces: difference of means against the pooled standard error |z| <= 3 (Welch), and the ratio of
+      the two standard deviations within [0.5, 2].  A systematic bias of an arithmetic shows as a shifted mean, extra noise as
+      a wider spread; a single trajectory can show neither.  Whether the control separates from float64 under this bar is
+      RECORDED (profiles/r06_trajectory_ensemble.txt), not asserted: 16-bit operands are a small bias next to this spread.
+
+Run on the GPU box: `python tools/trajectory.py [--steps 200] [--size 64] [--members 8] [--out profiles/r06_trajectory_ensemble.txt]`.
 oracle/ is used here as the yard-stick (a tool and a test, never the product path)."""
 import argparse
 import os
@@ -90,12 +94,29 @@ def start_state():
     return {k: v.detach().clone() for k, v in m.state_dict().items()}
 
 
-def run_engine(mode, state, x, t, xh, th, steps, checkpoints, device="cuda"):
+def perturbed_start(state, seed):
+    """the start weights moved by at most ONE float32 ulp each: every weight independently to its lower neighbour, itself or its
+    upper neighbour in float32 (probability 1/3 each; torch.nextafter), seeded.  seed None: the start itself.  The result is a
+    float32 state, so every arithmetic -- float64 included -- starts from exactly the same numbers."""
+    import torch
+    if seed is None:
+        return {k: v.detach().clone() for k, v in state.items()}
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in state.items():
+        d = torch.randint(-1, 2, v.shape, generator=g)
+        up = torch.nextafter(v, torch.full_like(v, float("inf")))
+        dn = torch.nextafter(v, torch.full_like(v, float("-inf")))
+        out[k] = torch.where(d > 0, up, torch.where(d < 0, dn, v)).clone()
+    return out
+
+
+def run_engine(mode, state, x, t, xh, th, steps, checkpoints, device="cuda", perturb_seed=None):
     import torch
     from xmm_superres_denoise.models import GeneratorRRDB_DN
     from xmm_superres_denoise.parallel import DataParallelTrainer
     m = GeneratorRRDB_DN(1, 1, NF, BLOCKS)
-    m.load_state_dict({k: v.clone() for k, v in state.items()})
+    m.load_state_dict(perturbed_start(state, perturb_seed))
     m = m.to(device)
     m.set_math(mode)
     tr = DataParallelTrainer(m, lr=LR, betas=BETAS)
@@ -119,7 +140,7 @@ def _round_sig(v, bits):
 
 def run_torch(dtype_name, state, x, t, xh, th, steps, checkpoints, device="cuda", perturb_seed=None, sig_bits=None):
     """the same graph, loss and optimizer in torch (oracle.torch_forward: the restatement the goldens pin to the reference);
-    perturb_seed: every start weight times (1 + d 2^-23), d uniform in {-1, 0, 1} (float64 runs: at most one fp32 ulp each);
+    perturb_seed: the start of perturbed_start(state, seed) (at most one fp32 ulp per weight);
     sig_bits: every conv's operands (input and weight) rounded to that many significant bits, forward and backward -- a stand-in for
     a math mode with too few operand bits (16: the two-term bf16 splits of rounds 1-2), to show what the bar catches"""
     import torch
@@ -127,12 +148,8 @@ def run_torch(dtype_name, state, x, t, xh, th, steps, checkpoints, device="cuda"
     dt = {"float64": torch.float64, "float32": torch.float32}[dtype_name]
     if device == "cpu":
         torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
-    # clone: .to() of a float32 CPU tensor to float32 CPU is the tensor itself, and Adam updates in place
-    st = {k: v.detach().clone().to(dtype=dt) for k, v in state.items()}
-    if perturb_seed is not None:
-        g = torch.Generator().manual_seed(perturb_seed)
-        for k in st:
-            st[k] = st[k] * (1.0 + (torch.randint(-1, 2, st[k].shape, generator=g).to(dt)) * 2.0 ** -23)
+    # (perturbed_start clones: .to() of a float32 CPU tensor to float32 CPU is the tensor itself, and Adam updates in place)
+    st = {k: v.to(dtype=dt) for k, v in perturbed_start(state, perturb_seed).items()}
     st = {k: v.to(device).requires_grad_(True) for k, v in st.items()}
     opt = torch.optim.Adam(list(st.values()), lr=LR, betas=BETAS, eps=1e-8)
     xd, td, xhd, thd = (torch.from_numpy(a).to(device=device, dtype=dt) for a in (x, t, xh, th))
@@ -160,143 +177,226 @@ def run_torch(dtype_name, state, x, t, xh, th, steps, checkpoints, device="cuda"
     return [float(v) for v in torch.stack(losses).double().cpu()], ck
 
 
-def run_all(steps=200, size=96, checkpoints=(10, 25, 50, 100, 200), cpu_f32=True, members=3, gpu_f32=True, log=print):
-    """-> {leg: (losses, {checkpoint: [psnr tile 0, psnr tile 1]})}; legs: 'float64', 'float64_ulp<i>' (members), 'float32_cpu',
-    'float32' (GPU, not deterministic), the three engine modes"""
-    checkpoints = tuple(c for c in checkpoints if c <= steps)
-    state = start_state()
-    x, t = denoise_pairs(4, size, 11)
-    xh, th = denoise_pairs(2, size, 23)
-    out = {}
-    legs = [("float64", lambda: run_torch("float64", state, x, t, xh, th, steps, checkpoints))]
-    legs += [(f"float64_ulp{i}", (lambda i=i: run_torch("float64", state, x, t, xh, th, steps, checkpoints, perturb_seed=100 + i))) for i in range(members)]
-    if cpu_f32:
-        legs.append(("float32_cpu", lambda: run_torch("float32", state, x, t, xh, th, steps, checkpoints, device="cpu")))
-    if gpu_f32:
-        legs.append(("float32", lambda: run_torch("float32", state, x, t, xh, th, steps, checkpoints)))
-        legs.append((CONTROL, lambda: run_torch("float32", state, x, t, xh, th, steps, checkpoints, sig_bits=16)))
-    legs += [(m, (lambda m=m: run_engine(m, state, x, t, xh, th, steps, checkpoints))) for m in ENGINE_MODES]
+def batched_forward(nf, blocks, st, x, sig_bits=None):
+    """the DN graph of oracle.torch_forward (generator_rrdb.py:66-69,130-137; rrdb_blocks.py:37-54,66-70; model.py:48-49) for K
+    MEMBERS AT ONCE: st[name] = [K, ...] stacked parameters, x = [K, B, 1, H, W] -> [K, B, 1, H, W].  A conv is im2col (F.unfold)
+    + one einsum over all members -- the same sums of products as F.conv2d in another order, which float64 does not notice
+    (tests/test_trajectory_host.py holds it to oracle.torch_forward at 1e-12) -- so K trajectories cost the kernel launches of one:
+    torch's float64 convs are launch-bound here (16 s per 200-step member, 82 ms per step of a 64 x 64 x 4 batch).
+    sig_bits: both conv operands rounded to that many significant bits (the negative control)."""
     import torch
-    start = {k: v.clone() for k, v in state.items()}
-    for name, fn in legs:
-        t0 = time.perf_counter()
-        out[name] = fn()
-        assert all(torch.equal(state[k], start[k]) for k in state), f"leg {name} modified the shared start state"
-        log(f"# {name}: {steps} steps in {time.perf_counter() - t0:.1f} s, loss {out[name][0][0]:.6f} -> {out[name][0][-1]:.6f}")
-    return out, checkpoints
+    import torch.nn.functional as F
+    K, B = x.shape[0], x.shape[1]
+    H, W = x.shape[-2:]
+
+    def conv(name, t):
+        w, b = st[name + ".weight"], st[name + ".bias"]
+        if sig_bits is not None:
+            t, w = _round_sig(t, sig_bits), _round_sig(w, sig_bits)
+        cols = F.unfold(t.reshape(K * B, t.shape[2], H, W), 3, padding=1).reshape(K, B, t.shape[2] * 9, H * W)
+        out = torch.einsum("koc,kbcl->kbol", w.reshape(K, w.shape[1], -1), cols) + b[:, None, :, None]
+        return out.reshape(K, B, w.shape[1], H, W)
+
+    fea = conv("conv_first", x)
+    cur = fea
+    for i in range(blocks):
+        rin = cur
+        for r in (1, 2, 3):
+            pre = f"rrdb.{i}.RDB{r}."
+            xs = [cur]
+            for c in (1, 2, 3, 4):
+                xs.append(F.leaky_relu(conv(pre + f"conv{c}", torch.cat(xs, 2)), 0.2))
+            cur = conv(pre + "conv5", torch.cat(xs, 2)) * 0.2 + cur
+        cur = cur * 0.2 + rin
+    fea = fea + conv("trunk_conv", cur)
+    out = conv("conv_last", fea) + x
+    return torch.clamp(torch.clamp(out, 0.0, 1.0), 0.0, 1.0)
 
 
-F32_ULP = 2.0 ** -23
+def run_torch_members(dtype_name, state, seeds, x, t, xh, th, steps, checkpoints, device="cuda", sig_bits=None):
+    """len(seeds) members of run_torch in ONE graph (batched_forward): stacked parameters, the sum of the members' mean-L1 losses
+    (each member's gradient is its own: no cross terms), one torch.optim.Adam over the stacked tensors (Adam is elementwise: K
+    independent Adams with the same step count).  -> [(losses, {checkpoint: [psnr per held-out tile]}) per member]"""
+    import torch
+    dt = {"float64": torch.float64, "float32": torch.float32}[dtype_name]
+    K = len(seeds)
+    starts = [perturbed_start(state, sd) for sd in seeds]
+    st = {k: torch.stack([s[k] for s in starts]).to(device=device, dtype=dt).requires_grad_(True) for k in state}
+    opt = torch.optim.Adam(list(st.values()), lr=LR, betas=BETAS, eps=1e-8)
+    xd, td, xhd, thd = (torch.from_numpy(a).to(device=device, dtype=dt)[None].expand(K, *a.shape) for a in (x, t, xh, th))
+    losses, ck = [], {}
+    for s in range(1, steps + 1):
+        opt.zero_grad(set_to_none=True)
+        per = (batched_forward(NF, BLOCKS, st, xd, sig_bits) - td).abs().mean(dim=(1, 2, 3, 4))      # [K] mean-L1 per member
+        per.sum().backward()
+        opt.step()
+        losses.append(per.detach())
+        if s in checkpoints:
+            with torch.no_grad():
+                y = batched_forward(NF, BLOCKS, st, xhd, sig_bits)
+                ck[s] = [psnr_db(y[k], thd[k]) for k in range(K)]
+    L = torch.stack(losses).double().cpu()      # [steps, K]
+    return [([float(v) for v in L[:, k]], {c: ck[c][k] for c in ck}) for k in range(K)]
 
 
+CONTROL = "control_16bit"   # the negative control: torch float32 with 16-bit conv operands -- must FAIL the step-10 bar
+REF = "float64"
 PRE_CHAOS_STEP = 10      # the divergence from float64 is still at rounding level: every fp32-class arithmetic sits at ~4e-6 dB / 1.5e-7 in loss
 ABS_BAR_DB = 1e-4        # ... so an ABSOLUTE bar means something here, and has teeth: conv operands rounded to 16 significant bits (the
 ABS_BAR_LOSS = 2e-6      #     two-term bf16 modes of rounds 1-2) are at 1e-3 dB / 3e-5 by step 10 (tools/trajectory_sigbits_probe.py), 20 bits at 1e-4
-CONTROL = "control_16bit"   # the negative control leg: torch float32 with 16-bit conv operands -- must FAIL the step-10 bar
-# Past the onset a distance to float64 is one draw from a wide distribution (the 24 data sets of tools/trajectory_scan.py: three fp32-class
-# modes end 0.02 - 1.6 dB apart); "2 x the largest of a handful of yard-sticks" alone would fail a legitimate run every ~10th time.
-# So the relative bar carries an absolute allowance per regime: what a run may differ by without that meaning anything.
-PSNR_FLOOR_DB = lambda c: 0.01 if c <= 50 else 1.0
-LOSS_FLOOR = lambda c: 1e-4 if c <= 50 else 5e-3        # (0.01 dB is 0.23 % of the mse: 1e-4 of a loss of 0.03 is the same size)
+Z_BAR = 3.0              # ensemble at the last step: |mean - mean_float64| <= Z_BAR pooled standard errors ...
+SPREAD_BAR = (0.5, 2.0)  # ... and sd / sd_float64 inside this interval
 
 
-def yard_sticks(res):
-    """every run that is NOT an engine mode and not the float64 reference: torch float32 (host cores, GPU) and the ulp-perturbed
-    float64 runs"""
-    return [k for k in res if k not in ENGINE_MODES and k != "float64" and not k.startswith("control_")]
+def member_seed(i):
+    """member 0 is the unperturbed start; member i > 0 the start moved by <= 1 fp32 ulp per weight under seed 100 + i"""
+    return None if i == 0 else 100 + i
 
 
-def verdict(res, checkpoints):
-    """rows (leg, checkpoint, |dloss|, |dpsnr| worst tile, bar |dloss|, bar |dpsnr|, ok) for the engine modes and the negative control.
-    Checkpoints <= PRE_CHAOS_STEP: the absolute bars ABS_BAR_LOSS / ABS_BAR_DB, whatever the yard-sticks do.  Later ones:
-    max(2 x the largest distance to float64 among yard_sticks(res), the regime's allowance)."""
-    ref_l, ref_p = res["float64"]
-    yards = yard_sticks(res)
+def run_ensemble(steps=200, size=64, members=8, engine_members=None, extra_f32_cpu=False, control_members=None, log=print):
+    """-> ({leg: [(losses, {checkpoint: [psnr tile 0, psnr tile 1]}) per member]}, checkpoints).  Legs: 'float64' (torch, the
+    reference distribution), the three engine modes, the 16-bit control; `members` runs each (the engine legs `engine_members`,
+    default the same; the control `control_members`, default the same -- 1 is enough for the step-10 bar), member i of every leg
+    from the SAME start (member_seed).  extra_f32_cpu: one torch float32 run on the host
+    cores from the unperturbed start (oneDNN; the round-5 yard-stick, for the record only)."""
+    import torch
+    checkpoints = tuple(c for c in (PRE_CHAOS_STEP, steps) if c <= steps)
+    state = start_state()
+    x, t = denoise_pairs(4, size, 11)
+    xh, th = denoise_pairs(2, size, 23)
+    ke = engine_members or members
+    kc = control_members or members
+    start = {k: v.clone() for k, v in state.items()}
+    each = lambda fn: (lambda seeds: [fn(sd) for sd in seeds])      # one run per member (the engine: one engine per run)
+    plan = [(REF, members, lambda seeds: run_torch_members("float64", state, seeds, x, t, xh, th, steps, checkpoints)),
+            (CONTROL, kc, lambda seeds: run_torch_members("float32", state, seeds, x, t, xh, th, steps, checkpoints, sig_bits=16))]
+    plan += [(m, ke, each(lambda sd, m=m: run_engine(m, state, x, t, xh, th, steps, checkpoints, perturb_seed=sd))) for m in ENGINE_MODES]
+    if extra_f32_cpu:
+        plan.append(("float32_cpu", 1, each(lambda sd: run_torch("float32", state, x, t, xh, th, steps, checkpoints, device="cpu", perturb_seed=sd))))
+    out = {}
+    for name, k, fn in plan:
+        t0 = time.perf_counter()
+        out[name] = fn([member_seed(i) for i in range(k)])
+        assert all(torch.equal(state[kk], start[kk]) for kk in state), f"leg {name} modified the shared start state"
+        last = [r[0][-1] for r in out[name]]
+        log(f"# {name}: {k} x {steps} steps in {time.perf_counter() - t0:.1f} s, loss {out[name][0][0][0]:.6f} -> {min(last):.6f} .. {max(last):.6f}")
+    return out, checkpoints
+
+
+def _mean_sd(v):
+    a = np.asarray(v, np.float64)
+    return float(a.mean()), float(a.std(ddof=1)) if a.size > 1 else 0.0
+
+
+def early_verdict(ens):
+    """rows (leg, |dloss|, |dPSNR| worst tile, ok) at PRE_CHAOS_STEP for member 0 (the unperturbed start) of every engine mode and of
+    the control against member 0 of float64: the absolute bars ABS_BAR_LOSS / ABS_BAR_DB"""
+    c = PRE_CHAOS_STEP
+    ref_l, ref_p = ens[REF][0]
     rows = []
     for leg in ENGINE_MODES + (CONTROL,):
-        if leg not in res:
+        if leg not in ens:
             continue
-        for c in checkpoints:
-            dl = abs(res[leg][0][c - 1] - ref_l[c - 1])
-            dp = max(abs(a - b) for a, b in zip(res[leg][1][c], ref_p[c]))
-            if c <= PRE_CHAOS_STEP:
-                bl, bp = ABS_BAR_LOSS, ABS_BAR_DB
-            else:
-                bl = max(2 * max(abs(res[y][0][c - 1] - ref_l[c - 1]) for y in yards), LOSS_FLOOR(c))
-                bp = max(2 * max(max(abs(a - b) for a, b in zip(res[y][1][c], ref_p[c])) for y in yards), PSNR_FLOOR_DB(c))
-            ok = dl <= bl and dp <= bp
-            rows.append((leg, c, dl, dp, bl, bp, ok))
+        l, p = ens[leg][0]
+        dl = abs(l[c - 1] - ref_l[c - 1])
+        dp = max(abs(a - b) for a, b in zip(p[c], ref_p[c]))
+        rows.append((leg, dl, dp, dl <= ABS_BAR_LOSS and dp <= ABS_BAR_DB))
     return rows
 
 
-def report(res, checkpoints, steps, size):
-    ref_l, ref_p = res["float64"]
-    lines = [f"DN 32 filters x 4 blocks, 4 tiles of {size}x{size}, mean-L1 + Adam(lr 1e-4, betas (0.9, 0.999)), {steps} steps from the "
-             "reference-default init (seed 0); 2 held-out tiles",
-             "",
-             "loss at step          " + "".join(f"{c:>14d}" for c in (1,) + tuple(checkpoints)),
-             ]
-    for leg in res:
-        lines.append(f"  {leg:<20s}" + "".join(f"{res[leg][0][c - 1]:14.8f}" for c in (1,) + tuple(checkpoints)))
-    lines += ["", "|loss - loss_float64|  " + "".join(f"{c:>14d}" for c in (1,) + tuple(checkpoints))]
-    for leg in res:
-        if leg != "float64":
-            lines.append(f"  {leg:<20s}" + "".join(f"{abs(res[leg][0][c - 1] - ref_l[c - 1]):14.3e}" for c in (1,) + tuple(checkpoints)))
-    lines += ["", "largest |loss - loss_float64| over all steps, and the step it occurs at"]
-    for leg in res:
-        if leg != "float64":
-            d = np.abs(np.array(res[leg][0]) - np.array(ref_l))
-            lines.append(f"  {leg:<20s}{d.max():14.3e}   step {int(d.argmax()) + 1}")
-    lines += ["", "PSNR (dB) of the held-out tiles at step" + "".join(f"{c:>22d}" for c in checkpoints)]
-    for leg in res:
-        lines.append(f"  {leg:<20s}                " + "".join(f"   {res[leg][1][c][0]:9.5f} {res[leg][1][c][1]:9.5f}" for c in checkpoints))
-    lines += ["", "|PSNR - PSNR_float64| (dB), worst tile" + "".join(f"{c:>14d}" for c in checkpoints)]
-    for leg in res:
-        if leg != "float64":
-            lines.append(f"  {leg:<20s}                " + "".join(
-                f"{max(abs(a - b) for a, b in zip(res[leg][1][c], ref_p[c])):14.3e}" for c in checkpoints))
-    rows = verdict(res, checkpoints)
+def ensemble_verdict(ens, step):
+    """rows (leg, statistic, n, mean, sd, z, sd ratio, ok) at `step` for every leg but float64, statistic in ('loss', 'psnr'): the
+    leg's members against float64's members -- z = (mean - mean_ref) / sqrt(sd^2 / n + sd_ref^2 / n_ref) (Welch), ratio = sd / sd_ref;
+    ok = |z| <= Z_BAR and SPREAD_BAR[0] <= ratio <= SPREAD_BAR[1].  'psnr' = mean of the held-out tiles' PSNR."""
+    def stat(leg, which):
+        if which == "loss":
+            return [r[0][step - 1] for r in ens[leg]]
+        return [float(np.mean(r[1][step])) for r in ens[leg]]
+    rows = []
+    for which in ("loss", "psnr"):
+        mr, sr = _mean_sd(stat(REF, which))
+        nr = len(ens[REF])
+        rows.append((REF, which, nr, mr, sr, 0.0, 1.0, True))
+        for leg in ens:
+            if leg == REF or len(ens[leg]) < 2:
+                continue
+            v = stat(leg, which)
+            m, sd = _mean_sd(v)
+            se = float(np.sqrt(sd * sd / len(v) + sr * sr / nr))
+            z = (m - mr) / se if se > 0 else (0.0 if m == mr else float("inf"))
+            ratio = sd / sr if sr > 0 else float("inf")
+            rows.append((leg, which, len(v), m, sd, z, ratio, abs(z) <= Z_BAR and SPREAD_BAR[0] <= ratio <= SPREAD_BAR[1]))
+    return rows
+
+
+def report(ens, checkpoints, steps, size):
+    """-> (text, early rows, ensemble rows)"""
     last = checkpoints[-1]
-    lines += ["", f"who is within 0.01 dB of float64 at step {last} (worst tile)?"]
-    for leg in res:
-        if leg != "float64":
-            d = max(abs(a - b) for a, b in zip(res[leg][1][last], ref_p[last]))
-            lines.append(f"  {leg:<20s}{d:10.4f} dB   {'yes' if d <= 0.01 else 'no'}")
-    lines += ["", f"bar: up to step {PRE_CHAOS_STEP}: |dloss| <= {ABS_BAR_LOSS:g} and |dPSNR| <= {ABS_BAR_DB:g} dB outright; later: max(2 x the largest distance among the yard-sticks ("
-              + ", ".join(yard_sticks(res)) + f"), the regime's allowance: {PSNR_FLOOR_DB(50)} dB / {LOSS_FLOOR(50):g} up to step 50, {PSNR_FLOOR_DB(51)} dB / {LOSS_FLOOR(51):g} beyond)",
-              f"  {'mode':<14s}{'step':>6s}{'|dloss|':>12s}{'bar':>12s}{'|dPSNR|':>12s}{'bar':>12s}   ok"]
-    for leg, c, dl, dp, bl, bp, ok in rows:
-        lines.append(f"  {leg:<14s}{c:6d}{dl:12.3e}{bl:12.3e}{dp:12.3e}{bp:12.3e}   {'yes' if ok else 'NO'}")
+    lines = [f"DN 32 filters x 4 blocks, 4 tiles of {size}x{size}, mean-L1 + Adam(lr 1e-4, betas (0.9, 0.999)), {steps} steps from the "
+             "reference-default init (seed 0); 2 held-out tiles; member 0 = that start, member i > 0 = every weight moved by <= 1 fp32 ulp (seed 100 + i)",
+             ""]
+    early = early_verdict(ens)
+    if PRE_CHAOS_STEP in checkpoints:
+        lines += [f"(1) step {PRE_CHAOS_STEP}, member 0 against float64's member 0: |dloss| <= {ABS_BAR_LOSS:g} and |dPSNR| (worst tile) <= {ABS_BAR_DB:g} dB outright",
+                  f"  {'leg':<16s}{'|dloss|':>12s}{'|dPSNR| dB':>14s}   ok"]
+        for leg, dl, dp, ok in early:
+            lines.append(f"  {leg:<16s}{dl:12.3e}{dp:14.3e}   {'yes' if ok else 'NO'}")
+        lines.append("")
+    lines += [f"(2) step {last}, ensembles: z = (mean - mean_float64) / pooled standard error, |z| <= {Z_BAR:g}; sd / sd_float64 in [{SPREAD_BAR[0]:g}, {SPREAD_BAR[1]:g}]",
+              f"  {'leg':<16s}{'stat':>6s}{'n':>4s}{'mean':>14s}{'sd':>12s}{'z':>9s}{'sd ratio':>10s}   ok"]
+    rows = ensemble_verdict(ens, last)
+    for leg, which, n, m, sd, z, ratio, ok in rows:
+        lines.append(f"  {leg:<16s}{which:>6s}{n:4d}{m:14.7f}{sd:12.3e}{z:9.2f}{ratio:10.2f}   {'-' if leg == REF else ('yes' if ok else 'NO')}")
+    lines += ["", f"members at step {last}: loss | PSNR (dB) of the two held-out tiles"]
+    for leg in ens:
+        for i, (l, p) in enumerate(ens[leg]):
+            lines.append(f"  {leg:<16s}{i:3d}  {l[last - 1]:.8f} | {p[last][0]:9.5f} {p[last][1]:9.5f}")
     lines.append("")
-    eng = [r for r in rows if r[0] in ENGINE_MODES]
-    lines.append("ALL ENGINE MODES WITHIN THE BAR" if all(r[-1] for r in eng) else "BAR MISSED: " + ", ".join(f"{r[0]}@{r[1]}" for r in eng if not r[-1]))
-    ctl = [r for r in rows if r[0] == CONTROL and r[1] <= PRE_CHAOS_STEP]
+    eng_early = [r for r in early if r[0] in ENGINE_MODES]
+    eng_ens = [r for r in rows if r[0] in ENGINE_MODES]
+    bad = [f"{r[0]}@{PRE_CHAOS_STEP}" for r in eng_early if not r[-1]] + [f"{r[0]}:{r[1]}@{last}" for r in eng_ens if not r[-1]]
+    lines.append("ALL ENGINE MODES WITHIN THE BAR" if not bad else "BAR MISSED: " + ", ".join(bad))
+    ctl = [r for r in early if r[0] == CONTROL]
     if ctl:
-        lines.append(f"negative control ({CONTROL}: torch float32 with conv operands rounded to 16 significant bits) at step {ctl[0][1]}: "
+        lines.append(f"negative control ({CONTROL}: torch float32 with conv operands rounded to 16 significant bits) at step {PRE_CHAOS_STEP}: "
                      + ("CAUGHT by the absolute bar" if not ctl[0][-1] else "NOT caught -- the bar has no teeth"))
-    return "\n".join(lines), rows
+    ctl_e = [r for r in rows if r[0] == CONTROL]
+    if ctl_e:
+        sep = [f"{r[1]} (z {r[5]:+.2f}, sd ratio {r[6]:.2f})" for r in ctl_e if not r[-1]]
+        lines.append(f"negative control at step {last}, ensemble of {ctl_e[0][2]}: " +
+                     ("SEPARATES from float64 in " + ", ".join(sep) if sep else
+                      "does NOT separate from float64 (" + ", ".join(f"{r[1]}: z {r[5]:+.2f}, sd ratio {r[6]:.2f}" for r in ctl_e) +
+                      ") -- at this horizon 16-bit operands are a bias smaller than the ensemble can resolve; the step-10 bar is what catches them"))
+    return "\n".join(lines), early, rows
+
+
+def passed(early, rows):
+    """the asserted bar: every engine mode inside (1) and (2), the control outside (1)"""
+    ok_modes = all(r[-1] for r in early if r[0] in ENGINE_MODES) and all(r[-1] for r in rows if r[0] in ENGINE_MODES)
+    ctl = [r for r in early if r[0] == CONTROL]
+    return ok_modes and (not ctl or not ctl[0][-1])
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--size", type=int, default=96)
-    ap.add_argument("--checkpoints", default="10,25,50,100,200")
-    ap.add_argument("--no-cpu-f32", action="store_true", help="skip torch float32 on the host cores (oneDNN)")
-    ap.add_argument("--members", type=int, default=4, help="float64 runs from starts perturbed by <= 1 fp32 ulp per weight")
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--members", type=int, default=8, help="runs per arithmetic (member 0 unperturbed, the others from starts moved by <= 1 fp32 ulp per weight)")
+    ap.add_argument("--engine-members", type=int, default=0, help="members of the engine legs (default: --members)")
+    ap.add_argument("--control-members", type=int, default=0, help="members of the 16-bit control (default: --members)")
+    ap.add_argument("--cpu-f32", action="store_true", help="also one torch float32 run on the host cores (oneDNN), for the record")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    cps = tuple(int(c) for c in a.checkpoints.split(","))
-    res, cps = run_all(a.steps, a.size, cps, not a.no_cpu_f32, a.members)
-    text, rows = report(res, cps, a.steps, a.size)
+    ens, cps = run_ensemble(a.steps, a.size, a.members, a.engine_members or None, a.cpu_f32, a.control_members or None)
+    text, early, rows = report(ens, cps, a.steps, a.size)
     print(text)
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         with open(a.out, "w") as f:
-            f.write(text + "\n\nloss per step (step, " + ", ".join(res) + ")\n")
+            f.write(text + "\n\nloss per step of member 0 (step, " + ", ".join(ens) + ")\n")
             for s in range(a.steps):
-                f.write(f"{s + 1:4d} " + " ".join(f"{res[k][0][s]:.9f}" for k in res) + "\n")
-    return 0 if all(r[-1] for r in rows if r[0] in ENGINE_MODES) else 1
+                f.write(f"{s + 1:4d} " + " ".join(f"{ens[k][0][0][s]:.9f}" for k in ens) + "\n")
+    return 0 if passed(early, rows) else 1      # non-zero too when the control is NOT caught at step 10 (a bar without teeth)
 
 
 if __name__ == "__main__":

@@ -7,6 +7,11 @@
 
 namespace xsd {
 
+// torch.clamp propagates NaN (clamp(nan, 0, 1) = nan; +-inf go to the bounds); fminf / fmaxf alone return the non-NaN operand and
+// would turn a NaN pixel into 0.  Identical to fminf(fmaxf(v, lo), hi) for every non-NaN v (round 6: tests/test_hip_abi_errors.py).
+__device__ __forceinline__ float clamp_nan(float v, float lo, float hi) { return v != v ? v : fminf(fmaxf(v, lo), hi); }
+
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeReduceParams
                 if (P.skip) v += sk;
                 if (P.addto) v += ad;
                 if (P.pre) P.pre[pix] = v;
-                if (P.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+                if (P.clamp01) v = clamp_nan(v, 0.f, 1.f);
                 P.y[pix] = v;
             }
 #pragma unroll
@@ -475,9 +480,9 @@ __global__ void mask_pad_normalize_kernel(MaskPadParams P)
             if (s > 1) v = v / (float)(s * s);
         }
         if (P.do_norm) {
-            v = fminf(fmaxf(v, 0.f), P.max_val) / P.max_val;
+            v = clamp_nan(v, 0.f, P.max_val) / P.max_val;
             v = stretch_fwd(v, P.mode);
-            v = fminf(fmaxf(v, 0.f), 1.f);
+            v = clamp_nan(v, 0.f, 1.f);
         }
         P.out[i] = v;
     }
@@ -489,12 +494,12 @@ __global__ void normalize_kernel(const float* in, float* out, long long n, float
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float v = in[i];
         if (!inverse) {
-            v = fminf(fmaxf(v, 0.f), max_val) / max_val;
+            v = clamp_nan(v, 0.f, max_val) / max_val;
             v = stretch_fwd(v, mode);
-            v = fminf(fmaxf(v, 0.f), 1.f);
+            v = clamp_nan(v, 0.f, 1.f);
         } else {
             v = max_val * stretch_inv(v, mode);
-            v = fminf(fmaxf(v, 0.f), max_val);
+            v = clamp_nan(v, 0.f, max_val);
         }
         out[i] = v;
     }

@@ -69,7 +69,7 @@ __device__ __forceinline__ void gconv_store(const GConvP& P, int b, int co, int 
     else o = (long long)b * P.ybs + co * HW + pix;
     if (P.accumulate) v += P.y[o];
     if (P.pre) P.pre[o] = v;
-    if (P.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+    if (P.clamp01) v = v != v ? v : fminf(fmaxf(v, 0.f), 1.f);      // torch.clamp propagates NaN
     P.y[o] = v;
 }
 

@@ -185,13 +185,16 @@ hipError_t run_probe(double seconds, double* tflops, double* ghz, hipStream_t st
         std::vector<unsigned long long> clk(2 * G);
         double total = 0.0;
         while (total < seconds * 1e3 && ms.size() < 4096) {
-            hipEventRecord(e0, st);
+            if ((e = hipEventRecord(e0, st)) != hipSuccess) { fail("hipEventRecord", e); break; }
             hipLaunchKernelGGL(mfma_stream_kernel<BF>, dim3(G), dim3(512), L::BYTES, st, d_src, d_out, d_clk, iters);
-            hipEventRecord(e1, st);
+            // a rejected launch (the 60 / 90 KiB LDS request, 512 threads) must not come back as "0 ms": inf TFLOP/s with rc = success
+            if ((e = hipGetLastError()) != hipSuccess) { fail("launch", e); break; }
+            if ((e = hipEventRecord(e1, st)) != hipSuccess) { fail("hipEventRecord", e); break; }
             if ((e = hipEventSynchronize(e1)) != hipSuccess) { fail("kernel", e); break; }
             float m = 0.f;
-            hipEventElapsedTime(&m, e0, e1);
-            hipMemcpy(clk.data(), d_clk, sizeof(unsigned long long) * 2 * G, hipMemcpyDeviceToHost);
+            if ((e = hipEventElapsedTime(&m, e0, e1)) != hipSuccess) { fail("hipEventElapsedTime", e); break; }
+            if (!(m > 0.f)) { fail("no elapsed time", hipErrorUnknown); break; }
+            if ((e = hipMemcpy(clk.data(), d_clk, sizeof(unsigned long long) * 2 * G, hipMemcpyDeviceToHost)) != hipSuccess) { fail("hipMemcpy", e); break; }
             std::vector<double> g(G);
             for (int i = 0; i < G; ++i) g[i] = clk[2 * i + 1] ? (double)clk[2 * i] / ((double)clk[2 * i + 1] * 10.0) : 0.0;    // s_memrealtime: 100 MHz
             std::nth_element(g.begin(), g.begin() + G / 2, g.end());

@@ -42,7 +42,7 @@ hipError_t launch_pack_shuffle_bias(const float* b, float* out, int planes, hipS
 static thread_local std::string g_err;
 static int fail(int code, const char* fmt, ...)
 {
-    char buf[512];
+    char buf[1024];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
@@ -187,6 +187,28 @@ static hipError_t launch_conv_any(xsd_engine* eng, ConvParams& p, hipStream_t s)
     return eng->math == 3 ? launch_conv3x3_s3x(p, s) : launch_conv3x3_mfma(p, s);
 }
 
+// Profile classes of xsd_profile_read (include/xsd.h): 0 conv (forward + input-gradient), 1 weight gradient; the HBM-bound kernels:
+// 2 edge_expand (1 -> 32), 3 edge_reduce (32 -> 1), 4 edge_wgrad, 5 L1 loss, 6 Adam, 7 clamp backward, 8 plane max |x| sweeps.
+// `bytes` is ALGORITHMIC traffic (SURVEY 8d rule: every operand once), `flop` 2 x MAC.
+enum { PK_CONV = 0, PK_WGRAD = 1, PK_EDGE_EXPAND = 2, PK_EDGE_REDUCE = 3, PK_EDGE_WGRAD = 4, PK_LOSS = 5, PK_ADAM = 6, PK_CLAMP_BWD = 7, PK_PLANE_AMAX = 8, PK_COUNT = 9 };
+static hipError_t run_edge_expand(xsd_engine* e, const EdgeExpandParams& p, hipStream_t s)
+{
+    const double px = (double)p.B * p.H * p.W;      // reads the image (4 B/px), writes the plane (128); + the plane it adds to; + the mask plane or its compact words
+    const double bytes = px * (4.0 + 128.0 + (p.accumulate ? 128.0 : 0.0) + (p.bits ? 4.0 : (p.mask ? 128.0 : 0.0)));
+    return prof_launch(e, PK_EDGE_EXPAND, 2.0 * 9 * 32 * px, bytes, s, [&]() { return launch_edge_expand(p, s); });
+}
+static hipError_t run_edge_reduce(xsd_engine* e, const EdgeReduceParams& p, hipStream_t s)
+{
+    const double px = (double)p.B * p.H * p.W;      // reads the plane (128 B/px) (+ skip, + addto), writes y (+ pre)
+    const double bytes = px * (128.0 + 4.0 + (p.skip ? 4.0 : 0.0) + (p.addto ? 4.0 : 0.0) + (p.pre ? 4.0 : 0.0));
+    return prof_launch(e, PK_EDGE_REDUCE, 2.0 * 9 * 32 * px, bytes, s, [&]() { return launch_edge_reduce(p, s); });
+}
+static hipError_t run_edge_wgrad(xsd_engine* e, const EdgeWgradParams& p, int which, float* dw, float* db, hipStream_t s, int cstride = 9)
+{
+    const double px = (double)p.B * p.H * p.W;      // reads the plane and the image once
+    return prof_launch(e, PK_EDGE_WGRAD, 2.0 * 9 * 32 * px, px * (128.0 + 4.0), s, [&]() { return launch_edge_wgrad(p, which, dw, db, s, cstride); });
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Plan builder
 // ------------------------------------------------------------------------------------------------------------
@@ -238,8 +260,24 @@ struct Builder {
         float* slot = new_slot();
         amax_valid[key] = slot;
         const int Bv = B;
-        pre.push_back([v, Bv, Hv, Wv, slot](hipStream_t s) { return launch_plane_amax(v, Bv, Hv, Wv, slot, s); });
+        xsd_engine* eng = e;
+        pre.push_back([eng, v, Bv, Hv, Wv, slot](hipStream_t s) { return prof_launch(eng, PK_PLANE_AMAX, 0.0, 128.0 * Bv * Hv * Wv, s, [&]() { return launch_plane_amax(v, Bv, Hv, Wv, slot, s); }); });
         return slot;
+    }
+
+    // The ONE launch that wrote the four pixel-shuffled views of a high-resolution plane published ONE maximum -- over all of its
+    // output chunks (conv3x3_h2x.hip: run_max) -- into each view's slot: that number IS the plane's max |x|, so the standard view
+    // of the plane (what HRconv and the weight gradient read) takes view 0's slot instead of a plane_amax sweep over 4 x the
+    // low-resolution pixels (round 6: 2.7 % of a batch-1 SR forward, 0.8 % at batch 16; results identical by construction)
+    void alias_shuffled(float* hr, int level)
+    {
+        if (e->math != 4) return;
+        OutDesc o; memset(&o, 0, sizeof(o));
+        shuf_out(o, hr, level, 0);
+        auto it = amax_valid.find(ViewKey(reinterpret_cast<uintptr_t>(o.p), o.rs, o.ps));
+        if (it == amax_valid.end()) return;
+        const PlaneIn v = std_in(hr, level + 1);
+        amax_valid[ViewKey(reinterpret_cast<uintptr_t>(v.p), v.rs, v.ps)] = it->second;
     }
 
     size_t plane_bytes(int level, int ch = 32) const
@@ -432,7 +470,12 @@ struct Builder {
         // one more part on the CUs the 8 m x 15 workgroups leave, when those can hold its 15 slots two per XCD (>= 16 spare CUs;
         // MI355X: exactly 16): no L2 sharing for it, no idle CU
         // (XSD_WGRAD_TAIL=0 (include/xsd.h): 8 m parts; same device 124.7 -> 125.2 tiles/s, the kernel -1.9 %)
-        { static const int tail = getenv("XSD_WGRAD_TAIL") ? atoi(getenv("XSD_WGRAD_TAIL")) : 1; if (tail && e->ncu - 120 * m >= 16) wp.nparts = 8 * m + 1; }
+#ifdef XSD_TEST_HOOKS      // only the hooks variant of the library (make hooks; include/xsd.h) reads the environment here
+        static const int tail = getenv("XSD_WGRAD_TAIL") ? atoi(getenv("XSD_WGRAD_TAIL")) : 1;
+#else
+        constexpr int tail = 1;
+#endif
+        if (tail && e->ncu - 120 * m >= 16) wp.nparts = 8 * m + 1;
         std::vector<Launch> pre;
         for (int i = 0; i < 5; ++i) {
             wp.x[i] = std_in(xpl[i], 0); wp.g[i] = std_in(Gp[i + 1], 0);      // g[n] = G_{n+1}, the gradient at conv n+1's output
@@ -500,7 +543,7 @@ struct Builder {
             p.B = B; p.H = H; p.W = W; p.out = fea; p.w = e->pk_edge + 0; p.mslope = 1.f;
             p.amax = report_slot(fea, 0);
             const long long boff = e->first_b;
-            F.push_back([eng, p, boff](hipStream_t s) mutable { p.s = eng->b_x; p.bias = eng->params + boff; return launch_edge_expand(p, s); });
+            F.push_back([eng, p, boff](hipStream_t s) mutable { p.s = eng->b_x; p.bias = eng->params + boff; return run_edge_expand(eng, p, s); });
         }
         float* cur = fea;
         for (int i = 0; i < blocks; ++i) {
@@ -567,6 +610,7 @@ struct Builder {
                 for (int n = 0; n < 4; ++n) { shuf_out(p.out[n], U[u], u, n); p.out[n].slope = 0.01f; }
                 p.bias = e->pk_sbias + e->up[u].sbias_off;
                 F.push_back(conv_launch(p, false, 0));
+                alias_shuffled(U[u], u);
                 release(const_cast<float*>(feat), u);
                 feat = U[u];
             }
@@ -585,7 +629,7 @@ struct Builder {
             p.B = B; p.H = H << lo; p.W = W << lo; p.f = sr ? H1 : T; p.w = e->pk_edge + 2 * 288; p.pre = pre; p.clamp01 = 1;
             const long long boff = e->last_b;
             F.push_back([eng, p, boff, sr](hipStream_t s) mutable {
-                p.bias = eng->params + boff; p.skip = sr ? nullptr : eng->b_x; p.y = eng->b_y; return launch_edge_reduce(p, s);
+                p.bias = eng->params + boff; p.skip = sr ? nullptr : eng->b_x; p.y = eng->b_y; return run_edge_reduce(eng, p, s);
             });
         }
         if (!train) return;
@@ -597,27 +641,27 @@ struct Builder {
         { // stage 0: output head
             std::vector<Launch>& S = e->bwd_stages[0];
             const long long npx = (long long)B * (H << lo) * (W << lo);
-            S.push_back([eng, pre, dpre, npx](hipStream_t s) { return launch_clamp_bwd(pre, eng->b_dy, dpre, npx, s); });
+            S.push_back([eng, pre, dpre, npx](hipStream_t s) { return prof_launch(eng, PK_CLAMP_BWD, 0.0, 12.0 * npx, s, [&]() { return launch_clamp_bwd(pre, eng->b_dy, dpre, npx, s); }); });
             { // conv_last weight grad
                 EdgeWgradParams p; memset(&p, 0, sizeof(p));
                 p.B = B; p.H = H << lo; p.W = W << lo; p.f = sr ? H1 : T; p.s = dpre; p.nblocks = EDGE_WGRAD_BLOCKS;
                 const long long wo = e->last_w, bo = e->last_b;
                 S.push_back([eng, p, wo, bo](hipStream_t s) mutable {
-                    p.partial = eng->edge_partial; return launch_edge_wgrad(p, 1, eng->b_grads + wo, eng->b_grads + bo, s);
+                    p.partial = eng->edge_partial; return run_edge_wgrad(eng, p, 1, eng->b_grads + wo, eng->b_grads + bo, s);
                 });
             }
             if (!sr) {
                 EdgeExpandParams p; memset(&p, 0, sizeof(p));
                 p.B = B; p.H = H; p.W = W; p.s = dpre; p.w = e->pk_edge + 3 * 288; p.out = dT; p.mslope = 1.f;
                 p.amax = report_slot(dT, 0);
-                S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
+                S.push_back([eng, p](hipStream_t s) { return run_edge_expand(eng, p, s); });
             } else {
                 float* GH = alloc(lo);
                 { // d(H1) masked by lrelu'(0.2)
                     EdgeExpandParams p; memset(&p, 0, sizeof(p));
                     p.B = B; p.H = H << lo; p.W = W << lo; p.s = dpre; p.w = e->pk_edge + 3 * 288; p.out = GH; p.mask = H1; p.mslope = 0.2f;
                     p.amax = report_slot(GH, lo);
-                    S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
+                    S.push_back([eng, p](hipStream_t s) { return run_edge_expand(eng, p, s); });
                 }
                 const float* hr_in = nup > 0 ? U[nup - 1] : T;
                 wgrad_launch(S, lo, {std_in(hr_in, lo)}, {std_in(GH, lo)}, e->hr, 1.f);
@@ -672,7 +716,11 @@ struct Builder {
                 const float* Gp[6] = {nullptr, dS[1], dS[2], dS[3], dS[4], dOut}; // G_c, c = 1..5
                 // one pair-list weight-gradient launch per dense block (f16x3 kernel) once every G exists, i.e. in front of dS_0
                 // (XSD_WGRAD_BLOCK=0 restores one launch per G for same-library A/Bs: 122.6 -> 125.6 tiles/s on one device, profiles/r04_ab_wgrad_block_launch.txt)
+#ifdef XSD_TEST_HOOKS
                 static const bool block_wgrad = getenv("XSD_WGRAD_BLOCK") ? atoi(getenv("XSD_WGRAD_BLOCK")) != 0 : true;
+#else
+                constexpr bool block_wgrad = true;
+#endif
                 const bool mega = block_wgrad && e->math >= 3 && block_parts_per_xcd(e->ncu) >= 1;      // both role-split weight-gradient kernels take pair lists; fewer than 120 CUs: one launch per G
                 for (int c = 4; c >= 0; --c) { // conv index c (0-based) = conv_{c+1}
                     std::vector<PlaneIn> xs;
@@ -710,14 +758,14 @@ struct Builder {
             p.B = B; p.H = H; p.W = W; p.f = dFea; p.nblocks = EDGE_WGRAD_BLOCKS;
             const long long wo = e->first_w, bo = e->first_b;
             S.push_back([eng, p, wo, bo](hipStream_t s) mutable {
-                p.s = eng->b_x; p.partial = eng->edge_partial; return launch_edge_wgrad(p, 0, eng->b_grads + wo, eng->b_grads + bo, s);
+                p.s = eng->b_x; p.partial = eng->edge_partial; return run_edge_wgrad(eng, p, 0, eng->b_grads + wo, eng->b_grads + bo, s);
             });
             EdgeReduceParams q; memset(&q, 0, sizeof(q));
             q.B = B; q.H = H; q.W = W; q.f = dFea; q.w = e->pk_edge + 1 * 288; q.clamp01 = 0;
             const float* skipg = sr ? nullptr : dpre;
             S.push_back([eng, q, skipg](hipStream_t s) mutable {
                 if (!eng->b_dx) return hipSuccess;
-                q.addto = skipg; q.y = eng->b_dx; return launch_edge_reduce(q, s);
+                q.addto = skipg; q.y = eng->b_dx; return run_edge_reduce(eng, q, s);
             });
         }
     }
@@ -792,7 +840,7 @@ struct Builder {
                 p.B = B; p.H = H; p.W = W; p.out = fea[q]; p.w = first_fwd(ch, q); p.mslope = 1.f; p.s_bs = CI * HW; p.accumulate = ch > 0;
                 const long long boff = e->first_b + 32 * q, xo = ch * HW;
                 F.push_back([eng, p, boff, xo, ch](hipStream_t s) mutable {
-                    p.s = eng->b_x + xo; p.bias = ch == 0 ? eng->params + boff : nullptr; return launch_edge_expand(p, s); });
+                    p.s = eng->b_x + xo; p.bias = ch == 0 ? eng->params + boff : nullptr; return run_edge_expand(eng, p, s); });
             }
         Tensor cur = fea;
         for (int i = 0; i < blocks; ++i) {
@@ -882,7 +930,7 @@ struct Builder {
                     p.y = eng->b_y + yo;
                     if (first) p.bias = eng->params + boff; else p.addto = p.y;
                     if (last) { p.skip = sr ? nullptr : eng->b_x + xo; p.pre = pre ? pre + yo : nullptr; p.clamp01 = 1; }
-                    return launch_edge_reduce(p, s);
+                    return run_edge_reduce(eng, p, s);
                 });
             }
         if (!train) return;
@@ -894,14 +942,14 @@ struct Builder {
         { // stage 0: output head
             std::vector<Launch>& S = e->bwd_stages[0];
             const long long npx = (long long)B * CO * HWo;
-            S.push_back([eng, pre, dpre, npx](hipStream_t s) { return launch_clamp_bwd(pre, eng->b_dy, dpre, npx, s); });
+            S.push_back([eng, pre, dpre, npx](hipStream_t s) { return prof_launch(eng, PK_CLAMP_BWD, 0.0, 12.0 * npx, s, [&]() { return launch_clamp_bwd(pre, eng->b_dy, dpre, npx, s); }); });
             for (int co = 0; co < CO; ++co)
             for (int q = 0; q < P; ++q) { // conv_last weight grad, 32 input channels of one output channel per launch (the bias gradient is the same sum every time)
                 EdgeWgradParams p; memset(&p, 0, sizeof(p));
                 p.B = B; p.H = H << lo; p.W = W << lo; p.f = headf[q]; p.s = dpre + co * HWo; p.s_bs = CO * HWo; p.nblocks = EDGE_WGRAD_BLOCKS;
                 const long long wo = e->last_w + ((long long)co * 32 * P + 32 * q) * 9, bo = e->last_b + co;
                 S.push_back([eng, p, wo, bo](hipStream_t s) mutable {
-                    p.partial = eng->edge_partial; return launch_edge_wgrad(p, 1, eng->b_grads + wo, eng->b_grads + bo, s);
+                    p.partial = eng->edge_partial; return run_edge_wgrad(eng, p, 1, eng->b_grads + wo, eng->b_grads + bo, s);
                 });
             }
             if (!sr) {
@@ -910,7 +958,7 @@ struct Builder {
                         EdgeExpandParams p; memset(&p, 0, sizeof(p));
                         p.B = B; p.H = H; p.W = W; p.s = dpre + co * HWo; p.s_bs = CO * HWo; p.w = last_bwd(co, q); p.out = dT[q]; p.mslope = 1.f;
                         p.accumulate = co > 0;
-                        S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
+                        S.push_back([eng, p](hipStream_t s) { return run_edge_expand(eng, p, s); });
                     }
             } else {
                 Tensor GH = alloc_t(lo);
@@ -920,7 +968,7 @@ struct Builder {
                         p.B = B; p.H = H << lo; p.W = W << lo; p.s = dpre + co * HWo; p.s_bs = CO * HWo; p.w = last_bwd(co, q); p.out = GH[q];
                         p.accumulate = co > 0; p.mslope = 1.f;
                         if (co == CO - 1) { p.mask = H1[q]; p.mslope = 0.2f; }
-                        S.push_back([p](hipStream_t s) { return launch_edge_expand(p, s); });
+                        S.push_back([eng, p](hipStream_t s) { return run_edge_expand(eng, p, s); });
                     }
                 const Tensor& hr_in = nup > 0 ? U[nup - 1] : T;
                 wgrad_all(S, lo, planes_of(hr_in, lo), GH, e->hr, 1.f);
@@ -1016,7 +1064,7 @@ struct Builder {
                     const int cstride = 9 * CI;
                     S.push_back([eng, p, wo, bo, xo, cstride](hipStream_t s) mutable {
                         p.s = eng->b_x + xo; p.partial = eng->edge_partial;
-                        return launch_edge_wgrad(p, 0, eng->b_grads + wo, eng->b_grads + bo, s, cstride);
+                        return run_edge_wgrad(eng, p, 0, eng->b_grads + wo, eng->b_grads + bo, s, cstride);
                     });
                 }
             const bool bcast = !sr && CI == 1 && CO > 1;  // DN with a one-channel x added to every output channel: dx += sum over the channels of dpre
@@ -1033,7 +1081,7 @@ struct Builder {
                         p.y = eng->b_dx + xo;
                         if (!first) p.addto = p.y;
                         if (last && skipg) p.skip = skipg + xo;
-                        return launch_edge_reduce(p, s);
+                        return run_edge_reduce(eng, p, s);
                     });
                 }
             if (bcast) {
@@ -1053,9 +1101,23 @@ static int ensure_plan(xsd_engine* e, int B, int H, int W, bool train)
     sizing.build();
     const size_t need = sizing.peak + 256;
     if (need > e->ws_bytes) {
+        // A batch that cannot fit is refused BEFORE the workspace the engine holds is given up: what the device could offer at best is
+        // its free memory plus that workspace.  The engine stays usable (same plan cache state as after any other shape change), and
+        // the message names the way out the reference has for this (rrdb_blocks.py:39-47: recompute instead of keeping activations).
+        const double gb = 1.0 / (1024.0 * 1024.0 * 1024.0);
+        const char* hint = train ? "; the saved activations of a training step are ~7.9 KB per low-resolution pixel -- construct the generator with "
+                                   "memory_efficient=True (chunked recompute, XSD_ME_CHUNK tiles at a time: the reference's rrdb_blocks.py:39-47 policy) or use a smaller batch"
+                                 : "; use a smaller batch per call";
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b + e->ws_bytes)
+            return fail(XSD_ERR_NOMEM, "a workspace of %.1f GiB for %d x %d x %d tiles does not fit this device (%.1f GiB free + %.1f GiB held by this engine of %.1f GiB)%s",
+                        need * gb, B, H, W, free_b * gb, e->ws_bytes * gb, total_b * gb, hint);
         if (e->ws) { hipDeviceSynchronize(); hipFree(e->ws); e->ws = nullptr; e->ws_bytes = 0; }
         hipError_t err = hipMalloc((void**)&e->ws, need);
-        if (err != hipSuccess) return fail(XSD_ERR_NOMEM, "workspace hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(err));
+        if (err != hipSuccess) {
+            (void)hipGetLastError();      // the failed allocation must not surface again as the next launch's error
+            return fail(XSD_ERR_NOMEM, "workspace hipMalloc(%.1f GiB for %d x %d x %d tiles) failed: %s%s", need * gb, B, H, W, hipGetErrorString(err), hint);
+        }
         e->ws_bytes = need;
     }
     if (e->amax_used + xsd_engine::AMAX_TAIL > e->amax_cap) {     // the sizing pass counted more max-|x| slots than are allocated
@@ -1109,10 +1171,12 @@ __global__ void pad_params_kernel(const float* real, float* padded, const PadDes
 extern "C" {
 
 const char* xsd_last_error(void) { return g_err.c_str(); }
-#ifdef XSD_DIAG
-const char* xsd_version(void) { return "xsd-hip gfx950 r4 (diagnostic variant)"; }
+#if defined(XSD_DIAG)
+const char* xsd_version(void) { return "xsd-hip gfx950 r6 (diagnostic variant)"; }
+#elif defined(XSD_TEST_HOOKS)
+const char* xsd_version(void) { return "xsd-hip gfx950 r6 (test-hooks variant)"; }
 #else
-const char* xsd_version(void) { return "xsd-hip gfx950 r4"; }
+const char* xsd_version(void) { return "xsd-hip gfx950 r6"; }
 #endif
 
 int xsd_create(const xsd_config* cfg, xsd_engine** out)
@@ -1134,9 +1198,11 @@ int xsd_create(const xsd_config* cfg, xsd_engine** out)
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) e->ncu = prop.multiProcessorCount;
-        // test hooks (include/xsd.h): plan as if the device had this many CUs; start the max-|x| slot array this small
+#ifdef XSD_TEST_HOOKS
+        // test hooks (include/xsd.h; hooks variant only): plan as if the device had this many CUs; start the max-|x| slot array this small
         if (const char* m = getenv("XSD_TEST_NCU")) { const int v = atoi(m); if (v >= 8 && v <= 4096) e->ncu = v; }
         if (const char* m = getenv("XSD_TEST_AMAX_CAP")) { const int v = atoi(m); if (v >= 2 * xsd_engine::AMAX_TAIL && v <= e->amax_cap) e->amax_cap = v; }
+#endif
     }
     // 32-channel planes (widths that are no multiple of 32 zero-padded to the next one), a few image channels
     const bool plane_path = cfg->num_filters <= 256 && cfg->in_channels <= 8 && cfg->out_channels <= 8 &&
@@ -1405,7 +1471,7 @@ int xsd_grad_range(const xsd_engine* e, int stage, int range_idx, int64_t* offse
 int xsd_l1_loss(xsd_engine* e, const float* dev_y, const float* dev_target, float* dev_dy_or_null, float* dev_loss, int64_t n, void* stream)
 {
     if (!e || !dev_y || !dev_target || !dev_loss || n <= 0) return fail(XSD_ERR_ARG, "bad argument");
-    HIPCHK(launch_l1_loss(dev_y, dev_target, dev_dy_or_null, e->loss_partial, 1024, dev_loss, n, (hipStream_t)stream));
+    HIPCHK(prof_launch(e, PK_LOSS, 0.0, (dev_dy_or_null ? 12.0 : 8.0) * n, (hipStream_t)stream, [&]() { return launch_l1_loss(dev_y, dev_target, dev_dy_or_null, e->loss_partial, 1024, dev_loss, n, (hipStream_t)stream); }));
     return XSD_OK;
 }
 
@@ -1469,9 +1535,10 @@ int xsd_loss_eval(xsd_loss_fn* f, const float* dev_y, const float* dev_target, f
 int xsd_adam_step(xsd_engine* e, float* dev_params, const float* dev_grads, float* dev_m, float* dev_v, int64_t n, int step,
                   float lr, float beta1, float beta2, float eps, float grad_scale, void* stream)
 {
-    (void)e;
     if (!dev_params || !dev_grads || !dev_m || !dev_v || n <= 0 || step < 1) return fail(XSD_ERR_ARG, "bad argument");
-    HIPCHK(launch_adam(dev_params, dev_grads, dev_m, dev_v, n, step, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream));
+    auto go = [&]() { return launch_adam(dev_params, dev_grads, dev_m, dev_v, n, step, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream); };
+    if (e) HIPCHK(prof_launch(e, PK_ADAM, 0.0, 28.0 * n, (hipStream_t)stream, go));      // reads p, g, m, v; writes p, m, v
+    else HIPCHK(go());
     return XSD_OK;
 }
 

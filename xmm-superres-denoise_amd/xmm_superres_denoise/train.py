@@ -31,10 +31,23 @@ def save_checkpoint(path: str, model: Model, trainer: DataParallelTrainer, epoch
 def load_checkpoint(path: str, model: Model, trainer: DataParallelTrainer | None = None) -> dict:
     """Reads a checkpoint with the loader that executes nothing from the file (`weights_only=True`: tensors, numbers, strings,
     dicts / lists of them).  What save_checkpoint writes is exactly that; a Lightning `.ckpt` carrying pickled objects
-    (callback states, hyper-parameter namespaces) is refused with torch's UnpicklingError rather than unpickled -- strip it
-    to {"state_dict": ...} with a trusted tool first."""
-    ck = torch.load(path, map_location="cpu", weights_only=True)
-    sd = {k[len("model."):]: v for k, v in ck["state_dict"].items() if k.startswith("model.")}
+    (callback states, hyper-parameter namespaces) is refused rather than unpickled: the error raised here names what is accepted
+    and the one-liner that reduces such a file to {"state_dict": ...} on a machine the user trusts."""
+    import pickle
+    try:
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:      # a Lightning .ckpt with objects under hyper_parameters / callbacks (INTEGRATION.md section 3)
+        raise RuntimeError(
+            f"{path}: the safe loader (weights_only=True) refused this checkpoint -- it holds pickled objects besides tensors and plain "
+            "containers (a genuine Lightning .ckpt carries them under `hyper_parameters` / `callbacks`).  Accepted: a file whose "
+            "`state_dict` maps the reference's key names (with or without Lightning's `model.` prefix) to tensors, optionally with this "
+            "driver's `adam` block.  Reduce it on a machine you trust: torch.save({'state_dict': torch.load(path, weights_only=False)"
+            f"['state_dict']}}, out).  ({e})") from e
+    if not isinstance(ck, dict) or "state_dict" not in ck:
+        raise RuntimeError(f"{path}: no `state_dict` in this checkpoint (keys: {sorted(ck) if isinstance(ck, dict) else type(ck).__name__})")
+    raw = ck["state_dict"]
+    # Lightning prefixes the generator's keys with the attribute name (`model.`, models/model.py:157-186); a bare state_dict is taken as is
+    sd = {k[len("model."):]: v for k, v in raw.items() if k.startswith("model.")} or dict(raw)
     if model.model is None:
         model.configure_model()
     model.model.load_state_dict(sd)
