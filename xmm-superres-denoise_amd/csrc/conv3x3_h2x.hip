@@ -106,18 +106,28 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
         return c;
     };
 
-    // plane / panel descriptors and the bias through LDS
-    unsigned long long* desc = reinterpret_cast<unsigned long long*>(smem + L::DESC);
-    if (tid < 5) {
-        desc[2 * tid] = reinterpret_cast<unsigned long long>(P.in[tid].p);
-        desc[2 * tid + 1] = (unsigned long long)P.in[tid].bs * 4ull;
-        desc[10 + tid] = reinterpret_cast<unsigned long long>(P.wstep[tid]);
-    }
-    float* bias_lds = reinterpret_cast<float*>(smem + L::BIAS);
-    if (tid < 160) bias_lds[tid] = (P.bias && tid < 32 * n_out) ? P.bias[tid] : 0.f;
-    __syncthreads();
-
+    // Prologue (round 6).  At the reference's own batch sizes (1 / 4 / 8: a 416 x 416 image is 338 tiles on 256 workgroups) a launch
+    // is 4 - 20 half-steps long and what precedes the first MFMA is a tenth of it.  Until round 6 that was FOUR dependent memory
+    // round trips behind each other -- descriptors + bias into LDS and a barrier; the max-|x| slots one by one (a pointer test, a
+    // scalar load and a wait each: the ISA showed up to six in a chain); then the first input tile and weight half-panel -- 6.5 us
+    // from kernel entry to the first barrier (tools/stamps_small.py).  Now everything that needs only the kernel arguments is
+    // requested at once: the slots as six independent scalar loads (absent inputs read the zero page), and the staging waves
+    // issue half-step 0's input loads and weight DMA from P.in[0] / P.wstep[0] directly BEFORE they fill the descriptor table.
     const float* zero = reinterpret_cast<const float*>(P.zero);
+
+    // plane / panel descriptors and the bias through LDS (written by threads of the staging waves, read after barrier A)
+    unsigned long long* desc = reinterpret_cast<unsigned long long*>(smem + L::DESC);
+    float* bias_lds = reinterpret_cast<float*>(smem + L::BIAS);
+    auto fill_tables = [&]() {
+        if (tid < 5) {
+            desc[2 * tid] = reinterpret_cast<unsigned long long>(P.in[tid].p);
+            desc[2 * tid + 1] = (unsigned long long)P.in[tid].bs * 4ull;
+            desc[10 + tid] = reinterpret_cast<unsigned long long>(P.wstep[tid]);
+        }
+        if (tid < 160) bias_lds[tid] = (P.bias && tid < 32 * n_out) ? P.bias[tid] : 0.f;
+    };
+    static_assert(160 <= X3_LT, "the table-filling threads belong to the staging waves");
+
     auto lds_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -126,22 +136,27 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
     const int rs0 = P.in[0].rs, ps0 = P.in[0].ps;
 
     // operand scales (powers of two) from the max |x| of the input planes and of the weight panels; every wave computes the
-    // same values from the same slots (scalar loads)
-    float sx, sw, inv_sx, inv_sw;
-    {
+    // same values from the same slots: six INDEPENDENT scalar loads (absent inputs read the zero page; the launcher rejects a
+    // missing slot of a live input), one wait.  The staging waves call this with half-step 0's vector loads already in flight.
+    // (Loading the slots at kernel entry and reducing here kept six more SGPRs live across the staging set-up: the catch-all
+    // instance spilled a register to scratch -- a scratch access is a vector-memory operation the counted waits do not know.)
+    float sx, sw, inv_sx, inv_sw, inv_s;
+    auto operand_scales = [&]() {
+        float a_in[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {           // static indices: a runtime index into the kernel arguments costs a scratch copy
+            const float* ap = (i < n_in && P.amax_in[i]) ? P.amax_in[i] : zero;
+            a_in[i] = *ap;
+        }
+        const float a_w = *(P.amax_w ? P.amax_w : zero);
         float ax = 0.f;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {       // static indices: a runtime index into the kernel arguments costs a scratch copy
-            const float* ap = P.amax_in[i];
-            const float a = (i < n_in && ap) ? *ap : (i < n_in ? 1.f : 0.f);
-            ax = a > ax ? a : ax;
-        }
-        const float aw = P.amax_w ? *P.amax_w : 1.f;
+        for (int i = 0; i < 5; ++i) ax = a_in[i] > ax ? a_in[i] : ax;
         ax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ax)));
         sx = scale_for_amax(ax, inv_sx);
-        sw = scale_for_amax(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, aw))), inv_sw);
-    }
-    const float inv_s = inv_sx * inv_sw;      // undoes both scales in the epilogue (exact)
+        sw = scale_for_amax(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a_w))), inv_sw);
+        inv_s = inv_sx * inv_sw;      // undoes both scales in the epilogue (exact)
+    };
 
     if (loader) {
         // ============================ staging waves ============================
@@ -243,16 +258,22 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + X3_XT) = lo;
         };
-        // prologue: half-step 0 into LDS, half-step 1 into the staging registers
+        // prologue: half-step 0 into LDS, half-step 1 into the staging registers.  Half-step 0 is (chunk 0, plane 0, half 0): its
+        // descriptors come straight from the kernel arguments (static indices), so its loads are in flight before the tables exist
         Cur cur = {0, 0, 0, 0};
         TileXY tcur = tile_of(0);
         tile_offsets(tcur);
         {
-            const i32x4 b0 = x_rsrc(cur, tcur, true), w0 = w_rsrc(cur, true);
+            const i32x4 b0 = make_rsrc(uniform64(reinterpret_cast<unsigned long long>(P.in[0].p) + (unsigned long long)tcur.b * ((unsigned long long)P.in[0].bs * 4ull)),
+                                       (abl & 16) ? 0u : plane_bytes);
+            const i32x4 w0 = make_rsrc(uniform64(reinterpret_cast<unsigned long long>(P.wstep[0])), X3_WSLOTS * 16u);
 #pragma unroll
             for (int r = 0; r < X3_XR; ++r) load_x_round(r, b0);
 #pragma unroll
             for (int r = 0; r < X3_WR; ++r) dma_w_round(r, w0, 0);
+            operand_scales();
+            fill_tables();
+            lds_barrier();                                                                 // (A) tables visible
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int r = 0; r < X3_XR; ++r) { asm volatile("" : "+v"(pin[r])); store_x_round(r, 0); }
@@ -341,6 +362,8 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
     }
 
     // ============================== MFMA waves ==============================
+    operand_scales();
+    lds_barrier();                                                                         // (A) tables visible
 #ifndef X3_MPRIO
 #define X3_MPRIO 2
 #endif

@@ -9,6 +9,7 @@
 // of them; wave w owns row w of each tile (32 pixels = 16 MFMA k-steps of 2 pixels).  Partial sums are written once
 // per workgroup ([nparts][n][j][9][32][32]) and combined in a fixed order by wgrad_reduce_kernel, so the result is
 // bitwise reproducible (no float atomics).
+#include <algorithm>
 #include "xsd_kernels.h"
 
 namespace xsd {
@@ -163,10 +164,11 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_mfma_kernel(const WgradPa
 // Block = 1024 threads = 16 waves over 256 consecutive elements: wave w sums partials [w*P/16, (w+1)*P/16) with one
 // float4 per lane (1 KiB contiguous per wave-load, 16 loads in flight), then the 16 wave sums are combined in fixed
 // order through LDS: deterministic, and the same summation order for any launch geometry.
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReduceParams R)
+__device__ __forceinline__ void wgrad_reduce_body(const WgradReduceParams& R)
 {
     __shared__ double red[16][256];
     const int total = R.n_g * R.n_in * 9 * 1024;        // multiple of 256
+    if ((int)blockIdx.x * 256 >= total) return;         // (multi-conv launches: the grid is the largest conv's)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int e4 = blockIdx.x * 256 + lane * 4;
     const long long stride = R.part_stride ? R.part_stride : (long long)R.n_g * R.n_in * 9 * 1024;
@@ -238,6 +240,20 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReducePar
     }
 }
 
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const WgradReduceParams R) { wgrad_reduce_body(R); }
+
+// The reductions of SEVERAL convs in one launch (blockIdx.y = conv): a dense block's pair-list weight-gradient launch is followed by
+// five of them (conv1 .. conv5), each 5 us of work behind 4 us of launch floor (tools/launch_floor_probe.hip) -- at the reference's
+// batch sizes (1 / 4 / 8) a train step's 60 reduce launches were 3.3 % / 1.3 % / 0.7 % of it.  Same blocks, same summation order per
+// element: bitwise the result of the separate launches.
+__global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const WgradReduceBatch RB)
+{
+    WgradReduceParams R = RB.r[0];
+#pragma unroll
+    for (int k = 1; k < WgradReduceBatch::MAXN; ++k) if ((int)blockIdx.y == k) R = RB.r[k];      // static indices into the kernel arguments
+    wgrad_reduce_body(R);
+}
+
 static PerDevice g_once;
 
 hipError_t launch_wgrad_mfma(const WgradParams& p, hipStream_t stream)
@@ -256,6 +272,15 @@ hipError_t launch_wgrad_reduce(const WgradReduceParams& r, hipStream_t stream)
 {
     const int total = r.n_g * r.n_in * 9 * 1024;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(1024), 0, stream, r);
+    return hipGetLastError();
+}
+
+hipError_t launch_wgrad_reduce_multi(const WgradReduceBatch& rb, hipStream_t stream)
+{
+    if (rb.n < 1 || rb.n > WgradReduceBatch::MAXN) return hipErrorInvalidValue;
+    int blocks = 0;
+    for (int k = 0; k < rb.n; ++k) blocks = std::max(blocks, (rb.r[k].n_g * rb.r[k].n_in * 9 * 1024 + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks, rb.n), dim3(1024), 0, stream, rb);
     return hipGetLastError();
 }
 

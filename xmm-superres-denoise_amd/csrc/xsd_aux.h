@@ -24,6 +24,7 @@ struct MaskPadParams {
 hipError_t launch_conv3x3_mfma(const ConvParams& p, hipStream_t stream);
 hipError_t launch_wgrad_mfma(const WgradParams& p, hipStream_t stream);
 hipError_t launch_wgrad_reduce(const WgradReduceParams& r, hipStream_t stream);
+hipError_t launch_wgrad_reduce_multi(const WgradReduceBatch& rb, hipStream_t stream);
 hipError_t launch_edge_expand(const EdgeExpandParams& p, hipStream_t s);
 hipError_t launch_edge_reduce(const EdgeReduceParams& p, hipStream_t s);
 hipError_t launch_add_channels(float* dst, const float* src, int C, long long HW, int B, hipStream_t s);

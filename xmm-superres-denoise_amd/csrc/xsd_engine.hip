@@ -509,13 +509,17 @@ struct Builder {
             wp.partial = eng->wg_partial; wp.bias_partial = eng->wg_bias_partial;
             wp.zero = eng->zero_page; wp.ablate = eng->ablate; wp.dbg = eng->dbg;
             hipError_t err = prof_launch(eng, 1, flop, bytes, s, [&]() { return launch_wgrad_split(eng->math, eng->ablate, wp, s); });
-            for (int n = 0; n < 5 && err == hipSuccess; ++n) {
+            if (err != hipSuccess) return err;
+            WgradReduceBatch rb;      // the five convs' fixed-order reductions as one launch (bitwise what five launches gave)
+            memset(&rb, 0, sizeof(rb));
+            rb.n = 5;
+            for (int n = 0; n < 5; ++n) {
                 WgradReduceParams r = rps[n];
                 r.partial = eng->wg_partial + (long long)fst[n] * PANEL_FLOATS; r.bias_partial = eng->wg_bias_partial + n * 32;
                 r.dw = eng->b_grads + wo[n]; r.db = eng->b_grads + bo[n];
-                err = launch_wgrad_reduce(r, s);
+                rb.r[n] = r;
             }
-            return err;
+            return launch_wgrad_reduce_multi(rb, s);
         });
     }
 

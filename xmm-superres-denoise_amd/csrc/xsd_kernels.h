@@ -148,6 +148,12 @@ struct WgradReduceParams {
     int pad_;
 };
 
+struct WgradReduceBatch {   // the reductions of up to five convs as ONE launch (a dense block's pair-list weight gradient)
+    static constexpr int MAXN = 5;
+    int n, pad_;
+    WgradReduceParams r[MAXN];
+};
+
 // pack descriptor: one conv's OIHW weights -> forward and transposed (dgrad) panels
 struct PackDesc {
     long long src_w;     // offset into flat params
