@@ -215,7 +215,7 @@ def pmc_traffic(math: str, batch: int, klass: str):
     """HBM bytes per launch from the committed PMC passes (tools/traffic.sh -> profiles/rNN_traffic_<math>.json, newest round
     first), valid only for the workload/batch they were collected on.  Returns (bytes, file) or (None, None): the figure is
     READ FROM THAT FILE, not measured in this run (PMC passes need rocprofv3 around the process)."""
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         rel = os.path.join("profiles", f"{rnd}_traffic_{math}.json")
         try:
             d = json.load(open(os.path.join(ROOT, rel)))

@@ -302,8 +302,11 @@ def test_full_size_forward_error_vs_float64():
 # batch slices, as at the bench batch of 32 -- every gradient tensor of every mode row-wise against float64 there too
 # -- and the bench batch itself (32 tiles, BASELINE configs[2]: 64 tiles per persistent workgroup), the same row-wise check; the
 # float64 yard-stick and the flip-candidate pass run on the GPU (chunks of two tiles), so the big cases take seconds
+# -- and (round 6) the REFERENCE's own operating points, 416 x 416 tiles (res/baseline_config.toml:36) at batch 1 (its default,
+# :13: 338 tiles on 256 persistent workgroups -- 82 of them walk a second tile) and batch 4 (res/configs/runs/*.yaml:26: 1352 tiles,
+# 5.28 per workgroup), where the launches are 4 - 60 half-steps long instead of the bench batch's 384
 BACKWARD_CASES = [(256, 1, 7101, False), (256, 1, 7201, False), (256, 1, 7301, False), (256, 1, 7401, False),
-                  (512, 2, 7501, True), (512, 8, 7701, True), (512, 32, 7801, True)]
+                  (512, 2, 7501, True), (512, 8, 7701, True), (512, 32, 7801, True), (416, 1, 7911, True), (416, 4, 7921, True)]
 _BWD_RESULTS = {}
 
 
