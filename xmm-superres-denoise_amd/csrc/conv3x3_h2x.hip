@@ -362,6 +362,10 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
     }
 
     // ============================== MFMA waves ==============================
+#ifdef XSD_DIAG   // the stamps' origin is kernel entry (slot 0 = entry -> barrier P, both prologue barriers inside)
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz: in-kernel clock = stamped cycles / this
+    unsigned long long t0 = __builtin_readcyclecounter();
+#endif
     operand_scales();
     lds_barrier();                                                                         // (A) tables visible
 #ifndef X3_MPRIO
@@ -609,8 +613,6 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
 
 #ifdef XSD_DIAG   // phase stamps (diagnostic library variant only; tools/stamps.py): accumulated shader cycles per phase
     unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
-    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz: in-kernel clock = stamped cycles / this
-    unsigned long long t0 = __builtin_readcyclecounter();
     const bool stamp = P.dbg != nullptr;
 #define X3_TICK(i) do { if (stamp) { const unsigned long long t_ = __builtin_readcyclecounter(); st[i] += t_ - t0; t0 = t_; } } while (0)
 #else
