@@ -199,6 +199,10 @@ int xsd_probe_mfma_stream(int fmt, double seconds, double* mfma_tflops, double* 
  * [7] s_memrealtime ticks, [8..12] staging wave, [13..15] youngest MFMA wave; weight gradient: [16] staging rounds,
  * [17] MFMA walk, [18] MFMA wave at the barrier, [19] staging wave at the barrier, [21] tiles. */
 int xsd_debug_stamps(xsd_engine* e, int enable, unsigned long long* out32);
+/* Diagnostic only (pure host arithmetic, no device needed): the number of workgroups a persistent split-mode conv launch over `ntiles`
+ * tiles uses on a device of `ncu` compute units (csrc/xsd_kernels.h: persistent_grid -- the full grid, or the balanced one when the
+ * launch has at most 8 rounds and its last round would fill at most 0.35 of the CUs). */
+int xsd_debug_persistent_grid(int ntiles, int ncu);
 /* Diagnostic only: hipOccupancyMaxActiveBlocksPerMultiprocessor of the split forward conv kernel at a dynamic LDS size. */
 int xsd_debug_occupancy(int lds_bytes);
 /* Diagnostic only: wall time (ms) of a grid of `grid` workgroups that each sleep `us` microseconds holding `lds_bytes` of LDS

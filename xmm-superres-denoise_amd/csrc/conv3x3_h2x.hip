@@ -735,7 +735,7 @@ hipError_t launch_conv3x3_h2x(const ConvParams& p, hipStream_t stream)
     const int tilesY = (p.H + X3_ROWS - 1) / X3_ROWS;
     const int ntiles = p.B * p.tilesX * tilesY;
     if (ntiles <= 0) return hipSuccess;
-    const dim3 g(ntiles < ncu ? ntiles : ncu), b(X3_THREADS);
+    const dim3 g(persistent_grid(ntiles, ncu)), b(X3_THREADS);
     // the launch's kind: the same for every output chunk, and no LeakyReLU where the instance has none
     int kind = x3_kind_of(p.out[0]);
     for (int j = 1; j < p.n_out; ++j) if (x3_kind_of(p.out[j]) != kind) kind = -1;

@@ -566,7 +566,7 @@ hipError_t launch_conv3x3_s3x(const ConvParams& p, hipStream_t stream)
     const int tilesY = (p.H + X3_ROWS - 1) / X3_ROWS;
     const int ntiles = p.B * p.tilesX * tilesY;
     if (ntiles <= 0) return hipSuccess;
-    const dim3 g(ntiles < ncu ? ntiles : ncu), b(X3_THREADS);
+    const dim3 g(persistent_grid(ntiles, ncu)), b(X3_THREADS);
     hipLaunchKernelGGL(conv3x3_s3x_kernel, g, b, X3_LDS_BYTES, stream, p);
     return hipGetLastError();
 }

@@ -1592,6 +1592,7 @@ int xsd_image_upsample(const float* dev_in, float* dev_out, int N, int H, int W,
     return XSD_OK;
 }
 
+int xsd_debug_persistent_grid(int ntiles, int ncu) { return (ntiles < 0 || ncu < 1) ? -1 : xsd::persistent_grid(ntiles, ncu); }
 int xsd_debug_occupancy(int lds_bytes) { return xsd::debug_conv_occupancy(lds_bytes); }
 float xsd_debug_residency_ms(int grid, int threads, int lds_bytes, int us) { return xsd::debug_residency_ms(grid, threads, lds_bytes, us); }
 

@@ -38,6 +38,33 @@ struct PerDevice {
     }
 };
 
+// Workgroups of a persistent conv launch over `ntiles` tiles on `ncu` compute units (one workgroup per CU; workgroup b walks tiles
+// b, b + G, b + 2G, ...).  The launch lasts as long as its longest workgroup: rounds = ceil(ntiles / ncu) tiles.  With the full grid
+// the LAST round is run by the `tail` = ntiles - (rounds - 1) ncu workgroups that have one tile more than the others.  When that tail
+// is sparse, the grid is instead the smallest one that needs no more rounds -- every workgroup gets the same number of tiles and the
+// CUs that would have run one tile fewer stay dark: 338 tiles (a 416 x 416 image, the reference's tile at its default batch 1) run as
+// 169 x 2 instead of 82 x 2 + 174 x 1.  Same critical path in tiles, measured faster -- the two-tile workgroups share the L2s, the
+// fabric and the power budget with 87 fewer neighbours for the whole launch instead of running the first round in a full house.
+// Round 6, same device, alternating, DN forward (profiles/r06_ab_balanced_grid.txt: 36 cells, batch 1 - 8 x tile 384 - 480), gain of
+// "always balance" over "never" by (rounds, tail / ncu):  2 rounds: 0.12 +20.6 %, 0.27 +9.2 %, 0.32 +5.4 %, 0.48 +0.8 %, 0.53 -1.3 %,
+// 0.76 -4.1 %;  3: 0.25 +5.4 %, 0.54 -3.1 %, 0.64 -3.8 %;  4: 0.06 +9.1 %, 0.38 -1.8 %, 0.52 -3.8 %;  5: 0.43 -2.2 %, 0.59 -3.2 %;
+// 6: 0.08 +3.1 %, 0.28 +0.2 %;  7: 0.12 +1.8 %, 0.75 -1.7 %;  8: 0.03 +1.8 %, 0.62 -1.7 %;  9 - 15 rounds: -0.2 ... -1.0 % everywhere.
+// Hence the rule: balance when the tail is at most 0.35 of the CUs and the launch has at most 8 rounds; otherwise the full grid (a
+// well-filled last round is better served by 256 workgroups than by 226 -- and the bench batch, 64 rounds, never takes this path).
+// Results are bitwise identical either way (a tile's arithmetic does not depend on which workgroup runs it).
+constexpr int BALANCED_GRID_MAX_ROUNDS = 8;
+inline int persistent_grid(int ntiles, int ncu)
+{
+    if (ntiles <= ncu) return ntiles;
+    const int rounds = (ntiles + ncu - 1) / ncu;
+    const int balanced = (ntiles + rounds - 1) / rounds;
+#if defined(XSD_GRID_MODE)      // experiment builds (make exp EXPFLAGS=-DXSD_GRID_MODE=0 | 1): never / always balance
+    return (XSD_GRID_MODE) ? balanced : ncu;
+#endif
+    const int tail = ntiles - (rounds - 1) * ncu;                       // 1 .. ncu workgroups would run the last round
+    return (rounds <= BALANCED_GRID_MAX_ROUNDS && 20 * tail <= 7 * ncu) ? balanced : ncu;
+}
+
 constexpr int TILE_H = 8;          // output rows per workgroup
 constexpr int TILE_W = 32;         // output cols per workgroup (= MFMA M)
 constexpr int HALO_W = TILE_W + 2; // 34

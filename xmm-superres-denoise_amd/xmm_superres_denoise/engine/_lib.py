@@ -82,7 +82,7 @@ ABI_SYMBOLS = [
     "xsd_last_error", "xsd_version", "xsd_create", "xsd_destroy", "xsd_param_count", "xsd_set_math", "xsd_get_math", "xsd_pack_weights",
     "xsd_forward", "xsd_backward", "xsd_backward_num_stages", "xsd_backward_stage", "xsd_grad_range",
     "xsd_l1_loss", "xsd_loss_create", "xsd_loss_destroy", "xsd_loss_eval", "xsd_loss_set_channels", "xsd_adam_step", "xsd_mask_pad_normalize", "xsd_compose_input", "xsd_normalize", "xsd_image_upsample",
-    "xsd_profile_enable", "xsd_profile_read", "xsd_probe_mfma_stream", "xsd_debug_stamps", "xsd_debug_occupancy", "xsd_debug_residency_ms", "xsd_test_conv3x3", "xsd_test_conv3x3_bwd",
+    "xsd_profile_enable", "xsd_profile_read", "xsd_probe_mfma_stream", "xsd_debug_stamps", "xsd_debug_persistent_grid", "xsd_debug_occupancy", "xsd_debug_residency_ms", "xsd_test_conv3x3", "xsd_test_conv3x3_bwd",
 ]
 
 
