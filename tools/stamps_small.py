@@ -23,11 +23,18 @@ x = torch.rand(B, 1, T, T, device='cuda')
 NCONV = 61
 tiles = B * ((T + 15) // 16) * ((T + 31) // 32)
 nwg = min(tiles, torch.cuda.get_device_properties(0).multi_processor_count)
+if os.environ.get("XSD_EXP_GRID"):      # an experiment build with a forced grid (-DXSD_GRID_ENV): that many workgroups, no plan-time tuning
+    nwg = min(tiles, int(os.environ["XSD_EXP_GRID"]))
 with torch.no_grad():
     for _ in range(3):
         m(x)
     torch.cuda.synchronize()
     eng = m._engine
+    if os.environ.get("XSD_EXP_GRID") and hasattr(eng, "set_grid_tuning"):
+        eng.set_grid_tuning(False)
+        for _ in range(3):
+            m(x)
+        torch.cuda.synchronize()
     out = (ctypes.c_uint64 * 32)()
     eng.L.xsd_debug_stamps(eng.h, 1, None)
     eng.profile_enable(True)

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <mutex>
 
 namespace xsd {
@@ -51,6 +52,12 @@ struct PerDevice {
 // 6: 0.08 +3.1 %, 0.28 +0.2 %;  7: 0.12 +1.8 %, 0.75 -1.7 %;  8: 0.03 +1.8 %, 0.62 -1.7 %;  9 - 15 rounds: -0.2 ... -1.0 % everywhere.
 // Hence the rule: balance when the tail is at most 0.35 of the CUs and the launch has at most 8 rounds; otherwise the full grid (a
 // well-filled last round is better served by 256 workgroups than by 226 -- and the bench batch, 64 rounds, never takes this path).
+// WHY (forced-grid stamps, profiles/r06_grid_scan.txt): the in-kernel clock of the batch-1 forward is 1.79 GHz with 256 workgroups
+// in flight, 1.95 with 169, 1.98 with 192, 2.22 with 128 -- off the AVERAGE power bound the chip still clocks by how many CUs run
+// matrix instructions at once, so dark CUs buy the busy ones clock.  The same scan found the one case where a THIRD round pays: two
+// (nearly) full rounds -- 512 tiles = one 512 x 512 image, or four 256 x 256 ones -- run 8.4 % / 8.5 % faster on three quarters of
+// the CUs (192 workgroups: 128 x 3 + 64 x 2 tiles; 184 - 200 within 1 %; the balanced 171 x 3: +4.2 %), 496 tiles +5.6 %; at a
+// 0.70 - 0.76 tail it is a wash (0 ... +2.7 %) and for 4 or 8 full rounds one round more loses 1.2 % / 3.4 %.
 // Results are bitwise identical either way (a tile's arithmetic does not depend on which workgroup runs it).
 constexpr int BALANCED_GRID_MAX_ROUNDS = 8;
 inline int persistent_grid(int ntiles, int ncu)
@@ -58,10 +65,15 @@ inline int persistent_grid(int ntiles, int ncu)
     if (ntiles <= ncu) return ntiles;
     const int rounds = (ntiles + ncu - 1) / ncu;
     const int balanced = (ntiles + rounds - 1) / rounds;
-#if defined(XSD_GRID_MODE)      // experiment builds (make exp EXPFLAGS=-DXSD_GRID_MODE=0 | 1): never / always balance
+#if defined(XSD_GRID_ENV)       // experiment builds only (make exp EXPFLAGS=-DXSD_GRID_ENV): the grid is min(ntiles, $XSD_EXP_GRID) -- tools/grid_scan.sh
+    if (const char* g_ = getenv("XSD_EXP_GRID")) { const int v_ = atoi(g_); if (v_ > 0) return ntiles < v_ ? ntiles : (v_ < ncu ? v_ : ncu); }
+#endif
+#if defined(XSD_GRID_MODE)      // experiment builds (make exp EXPFLAGS=-DXSD_GRID_MODE=0 | 1 | 2): never / always balance / one round MORE than needed
+    if ((XSD_GRID_MODE) == 2) return (ntiles + rounds) / (rounds + 1);
     return (XSD_GRID_MODE) ? balanced : ncu;
 #endif
     const int tail = ntiles - (rounds - 1) * ncu;                       // 1 .. ncu workgroups would run the last round
+    if (rounds == 2 && 10 * tail >= 9 * ncu) return 3 * ncu / 4;        // two (nearly) full rounds: three rounds on three quarters of the CUs
     return (rounds <= BALANCED_GRID_MAX_ROUNDS && 20 * tail <= 7 * ncu) ? balanced : ncu;
 }
 
