@@ -58,6 +58,11 @@ struct PerDevice {
 // (nearly) full rounds -- 512 tiles = one 512 x 512 image, or four 256 x 256 ones -- run 8.4 % / 8.5 % faster on three quarters of
 // the CUs (192 workgroups: 128 x 3 + 64 x 2 tiles; 184 - 200 within 1 %; the balanced 171 x 3: +4.2 %), 496 tiles +5.6 %; at a
 // 0.70 - 0.76 tail it is a wash (0 ... +2.7 %) and for 4 or 8 full rounds one round more loses 1.2 % / 3.4 %.
+// A third scan (near-full grids, sparse tails, 3 - 8 rounds) placed the optimum of the multi-round launches BETWEEN the balanced and
+// the full grid -- 1352 tiles (four 416 x 416 images, the reference's training batch): 226 (balanced) 491.5, 232 496.4, 240 502.5, 248 500.9,
+// 256 490.9 tiles/s; 1300: 217 -> 510.4, 232 -> 522.3, 256 -> 492.4; 1568: 224 -> 429.1, 240 -> 438.7; 1800: 225 -> 379.3, 240 -> 384.2; 576:
+// 192 -> 454, 232 -> 468.5; 1350: 225 -> 368.7, 240 -> 378.1 -- the midpoint of the two is within 0.5 % of the best in all seven (+1.3 ... +2.5 %
+// over balanced); with two rounds the balanced grid stays (338 tiles: 169 -> 300, 176 - 192 -> 306, 208 -> 298).
 // Results are bitwise identical either way (a tile's arithmetic does not depend on which workgroup runs it).
 constexpr int BALANCED_GRID_MAX_ROUNDS = 8;
 inline int persistent_grid(int ntiles, int ncu)
@@ -74,7 +79,8 @@ inline int persistent_grid(int ntiles, int ncu)
 #endif
     const int tail = ntiles - (rounds - 1) * ncu;                       // 1 .. ncu workgroups would run the last round
     if (rounds == 2 && 10 * tail >= 9 * ncu) return 3 * ncu / 4;        // two (nearly) full rounds: three rounds on three quarters of the CUs
-    return (rounds <= BALANCED_GRID_MAX_ROUNDS && 20 * tail <= 7 * ncu) ? balanced : ncu;
+    if (rounds > BALANCED_GRID_MAX_ROUNDS || 20 * tail > 7 * ncu) return ncu;
+    return rounds == 2 ? balanced : (balanced + ncu) / 2;                // a sparse last round: the balanced grid (two rounds), midway to the full one (three to eight)
 }
 
 constexpr int TILE_H = 8;          // output rows per workgroup
