@@ -102,3 +102,32 @@ def test_scale_report_decomposes_an_efficiency(tmp_path):
     assert abs(eff - four["value"] / (4 * 128.0)) < 1e-3
     assert abs(mean_rate - 250.0 / (sum(ms) / 4)) < 1e-3 and abs(slow - (sum(ms) / 4) / 270.0) < 1e-3 and abs(barrier - 270.0 / 271.0) < 1e-3
     assert abs(eff - mean_rate * slow * barrier) < 2e-3 and comm == 0.2
+
+
+def test_roofline_block_edge_kernels_and_tile_size():
+    """bench.roofline_block (round 6): the HBM-bound kernels of the step -- profile classes 2.. of include/xsd.h -- each as algorithmic
+    bytes / event time against 8 TB/s; at a tile size other than BASELINE's 512 the whole-step figures scale with the pixels and no
+    committed PMC traffic is quoted (those files were collected at 512 x 512, batch 32)."""
+    import bench
+    px = 32 * 512 * 512
+    prof = {k: {"ms": 0.0, "launches": 0, "flop": 0.0, "bytes": 0.0} for k in range(len(bench.PROFILE_CLASSES))}
+    prof[0] = {"ms": 170.0, "launches": 122, "flop": 122 * 458.79e9, "bytes": 122 * 4.26e9}
+    prof[1] = {"ms": 76.0, "launches": 13, "flop": 13 * 2.153e12, "bytes": 13 * 10.08e9}
+    prof[2] = {"ms": 0.75, "launches": 2, "flop": 0.0, "bytes": 2 * px * 132.0}            # edge_expand: 2.95 TB/s
+    prof[6] = {"ms": 0.013, "launches": 1, "flop": 0.0, "bytes": 28.0 * 1670657}            # Adam over the 1.67 M parameters
+    r = bench.roofline_block("f16x3", prof, 32, "dn", True, 1, 126.0)
+    assert r["bound"] == "mfma" and abs(r["frac"] - (122 * 458.79e9 / 0.170 / 1e12) / (2500.0 / 3)) < 1e-9
+    e = r["edge"]
+    assert set(e) == {"edge_expand", "adam", "share_of_profiled_kernel_time"}              # classes that did not run are not listed
+    assert abs(e["edge_expand"]["achieved"] - 2 * px * 132.0 / 0.75e-3 / 1e9) < 1e-6 and e["edge_expand"]["peak"] == 8000.0
+    assert abs(e["edge_expand"]["frac"] - e["edge_expand"]["achieved"] / 8000.0) < 1e-12 and abs(e["edge_expand"]["avg_launch_us"] - 375.0) < 1e-9
+    assert abs(e["share_of_profiled_kernel_time"] - 0.763 / (170.0 + 76.0 + 0.763)) < 1e-9
+    assert r["traffic_from"] is None or "profiles/" in r["traffic_from"]                    # 512 x 512, batch 32, DN train: the committed PMC file, if any
+    w512 = r["whole_step"]
+    r416 = bench.roofline_block("f16x3", prof, 32, "dn", True, 1, 126.0, True, None, 416)
+    assert r416["traffic"] is None and r416["traffic_from"] is None                         # no PMC figure off the size it was collected at
+    s = (416 * 416) / (512 * 512)
+    assert abs(r416["whole_step"]["algorithmic_GBps"] - s * w512["algorithmic_GBps"]) < 1e-6
+    assert abs(r416["whole_step"]["algorithmic_TFLOPs"] - s * w512["algorithmic_TFLOPs"]) < 1e-9
+    other = bench.roofline_block("f16x3", prof, 32, "dn", True, 1, 126.0, False)           # another width: no whole-step figures, the edge block stays
+    assert "whole_step" not in other and "edge" in other

@@ -149,6 +149,19 @@ def test_bench_line_reports_package_power_and_clock():
     assert abs(r["frac_of_sustained"] - r["achieved"] / r["sustained_peak"]) < 1e-9 and r["frac"] < r["frac_of_sustained"] < 1.0, r
     assert abs(d["psnr_delta_db"]) < 0.01 and len(d["psnr"]["delta_db_per_tile"]) == 2
     assert d["comm_ms_exposed"] == 0.0 and "per_rank" not in d        # one process, no process group: no exchange
+    # round 6: north_star names the SuperRes PSNR -- every line carries both generators' figures
+    assert abs(d["psnr"]["sr_delta_db"]) < 0.01 and d["psnr"]["dn_delta_db"] == d["psnr_delta_db"] and len(d["psnr"]["sr"]["delta_db_per_tile"]) == 2
+    # ... the HBM-bound kernels of the step, each against 8 TB/s ("report both ... per kernel")
+    edge = r["edge"]
+    for k in ("edge_expand", "edge_reduce", "edge_wgrad", "l1_loss", "adam", "clamp_bwd"):
+        assert edge[k]["bound"] == "hbm" and edge[k]["peak"] == 8000.0 and 500 < edge[k]["achieved"] < 8000 and edge[k]["launches"] >= 12, (k, edge[k])
+        assert abs(edge[k]["frac"] - edge[k]["achieved"] / 8000.0) < 1e-9
+    assert edge["edge_expand"]["launches"] == 24 and edge["adam"]["launches"] == 12      # conv_first forward + conv_last input-gradient per step; one Adam
+    assert abs(edge["edge_expand"]["algorithmic_bytes_per_launch"] - 32 * 512 * 512 * 132.0) < 1.0
+    assert 0.001 < edge["share_of_profiled_kernel_time"] < 0.03
+    # ... and the same K steps without the per-launch events of the roofline block: within 2 % at this batch, never slower than 1 % of the headline
+    u = d["unprofiled"]
+    assert 0.99 * d["value"] < u["value"] < 1.02 * d["value"] and abs(u["ms_per_step"] - 1e3 * 32 / u["value"]) < 1e-6, u
 
 
 def test_train_driver_one_rank_over_rccl(tmp_path):
