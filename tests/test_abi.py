@@ -195,7 +195,7 @@ def test_product_library_reads_no_test_hook_from_the_environment():
 def test_persistent_conv_grid_rule():
     """csrc/xsd_kernels.h: persistent_grid (round 6; the measured table is profiles/r06_ab_balanced_grid.txt).  A persistent conv launch
     uses the full grid unless the launch is short (<= 8 rounds) AND its last round would be sparse (<= 0.35 of the CUs): then the smallest
-    grid with the same number of rounds (two rounds) or the midpoint between that and the full grid (three to eight); or it is two (nearly)
+    grid with the same number of rounds plus a fifth of the way to the full grid (two rounds) or the midpoint of the two (three to eight); or it is two (nearly)
     full rounds: then three quarters of the CUs.  Pure host arithmetic behind a diagnostic C-ABI entry: no device needed."""
     import ctypes
     from xmm_superres_denoise.engine import _lib
@@ -203,7 +203,7 @@ def test_persistent_conv_grid_rule():
     g = L.xsd_debug_persistent_grid
     g.argtypes = [ctypes.c_int, ctypes.c_int]
     assert g(200, 256) == 200 and g(256, 256) == 256 and g(1, 256) == 1 and g(0, 256) == 0
-    assert g(338, 256) == 169            # a 416 x 416 image (the reference's tile), batch 1: 2 rounds, tail 82 / 256 = 0.32 -> 169 x 2
+    assert g(338, 256) == 186            # a 416 x 416 image (the reference's tile), batch 1: 2 rounds, tail 82 / 256 = 0.32 -> a fifth of the way from 169 x 2 to the full grid
     assert g(1352, 256) == 241           # batch 4: 6 rounds, tail 72 / 256 = 0.28 -> midway between the balanced grid (226) and the full one
     assert g(512, 256) == 192            # 512 x 512, batch 1: two full rounds -> three rounds on three quarters of the CUs (+8.4 % measured)
     assert g(496, 256) == 192 and g(487, 256) == 192 and g(486, 256) == 256      # ... from a 0.9 tail up (10 * tail >= 9 * ncu)
@@ -213,7 +213,7 @@ def test_persistent_conv_grid_rule():
     assert g(2704, 256) == 256           # batch 8: 11 rounds -> full
     assert g(16384, 256) == 256          # the bench batch (32 x 512 x 512): 64 rounds
     assert g(2 * 256 + 89, 256) == ((2 * 256 + 89 + 2) // 3 + 256) // 2 and g(2 * 256 + 90, 256) == 256      # the 0.35 boundary: 20 * tail <= 7 * ncu
-    assert g(256 + 89, 256) == (256 + 89 + 1) // 2 and g(256 + 90, 256) == 256                                  # ... with two rounds: the balanced grid itself
+    assert g(256 + 89, 256) == 173 + (256 - 173) // 5 and g(256 + 90, 256) == 256                               # ... with two rounds: a fifth of the way up from the balanced grid
     for ncu in (64, 120, 256, 304):
         for nt in range(0, 12 * ncu, 7):
             G = g(nt, ncu)

@@ -62,7 +62,7 @@ struct PerDevice {
 // the full grid -- 1352 tiles (four 416 x 416 images, the reference's training batch): 226 (balanced) 491.5, 232 496.4, 240 502.5, 248 500.9,
 // 256 490.9 tiles/s; 1300: 217 -> 510.4, 232 -> 522.3, 256 -> 492.4; 1568: 224 -> 429.1, 240 -> 438.7; 1800: 225 -> 379.3, 240 -> 384.2; 576:
 // 192 -> 454, 232 -> 468.5; 1350: 225 -> 368.7, 240 -> 378.1 -- the midpoint of the two is within 0.5 % of the best in all seven (+1.3 ... +2.5 %
-// over balanced); with two rounds the balanced grid stays (338 tiles: 169 -> 300, 176 - 192 -> 306, 208 -> 298).
+// over balanced); with two rounds the optimum sits a little above the balanced grid (338 tiles: 169 -> 300, 176 - 192 -> 306, 208 -> 298).
 // Results are bitwise identical either way (a tile's arithmetic does not depend on which workgroup runs it).
 constexpr int BALANCED_GRID_MAX_ROUNDS = 8;
 inline int persistent_grid(int ntiles, int ncu)
@@ -80,7 +80,9 @@ inline int persistent_grid(int ntiles, int ncu)
     const int tail = ntiles - (rounds - 1) * ncu;                       // 1 .. ncu workgroups would run the last round
     if (rounds == 2 && 10 * tail >= 9 * ncu) return 3 * ncu / 4;        // two (nearly) full rounds: three rounds on three quarters of the CUs
     if (rounds > BALANCED_GRID_MAX_ROUNDS || 20 * tail > 7 * ncu) return ncu;
-    return rounds == 2 ? balanced : (balanced + ncu) / 2;                // a sparse last round: the balanced grid (two rounds), midway to the full one (three to eight)
+    // a sparse last round: a fifth of the way from the balanced grid to the full one with two rounds (338 tiles: 169 -> 300.0, 176 -> 306.1,
+    // 192 -> 306.0, 208 -> 297.9 tiles/s; 288 tiles: 144 -> 336.6, 160 -> 341.2, 169 -> 342.6, 176 -> 339.8), midway with three to eight
+    return rounds == 2 ? balanced + (ncu - balanced) / 5 : (balanced + ncu) / 2;
 }
 
 constexpr int TILE_H = 8;          // output rows per workgroup
