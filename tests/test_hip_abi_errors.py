@@ -139,6 +139,33 @@ def test_batch_that_cannot_fit_fails_cleanly_and_memory_efficient_trains_it():
     assert float((tr16.grads - trm2.grads).abs().max()) <= 2e-6 * scale + 1e-12
 
 
+def test_non_finite_first_pixel_does_not_leak_through_the_zero_padding():
+    """The 32 -> 1 edge conv fetched out-of-image taps from the image's FIRST pixel and multiplied them by 0 -- 0 * nan = nan: a NaN at
+    pixel (0, 0) came out along every border of the tile.  Now a select.  The set of non-finite outputs equals the oracle's: the 19 x 19
+    corner the 18 convs reach from (0, 0)."""
+    import numpy as np
+    import gen_common as gc
+    from oracle import oracle
+    from util_hip import build_module
+    state = gc.make_state("dn", 32, 1, 977)
+    m = build_module("dn", 1, 1, state)
+    x = gc.make_input((2, 1, 80, 72), 978)
+    x[1, 0, 0, 0] = np.nan
+    with np.errstate(invalid="ignore", over="ignore"):
+        yo = oracle.forward("dn", 32, 1, oracle.flatten_state(state), x)
+    bad_o = ~np.isfinite(yo)
+    assert bad_o[0].sum() == 0 and bad_o[1].sum() == 19 * 19
+    for mode in ("f16x3", "bf16x6", "fp32"):
+        m.set_math(mode)
+        xd = torch.from_numpy(x).cuda().requires_grad_(True)
+        y = m(xd)
+        assert np.array_equal(~np.isfinite(y.detach().cpu().numpy()), bad_o), mode
+        # ... and backward: dL/dx of the clean tile is finite everywhere (conv_first's input-gradient is the same 32 -> 1 kernel)
+        y[0].sum().backward()
+        g = xd.grad.cpu().numpy()
+        assert np.isfinite(g[0]).all(), mode
+
+
 @pytest.mark.parametrize("bad", ["nan", "inf", "-inf"])
 def test_non_finite_input_propagates_like_the_reference(bad):
     """One non-finite input pixel: torch propagates it through every conv it reaches (a 3 x 3 conv spreads it by one pixel, 0 * nan = nan,

@@ -23,6 +23,11 @@ __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams
 {
     // One image row per block iteration: the three rows of s around it are staged zero-padded in LDS, the thread's 9 x 4
     // weights live in registers, and the row is swept two pixels per thread at a time (no per-pixel division).
+    // (Round 6 measured this kernel at 2.8 - 3.7 TB/s against the 6.85 TB/s a pure write stream reaches here (tools/hbm_stream_probe.py)
+    // and tried two rewrites, same device, alternating: a 32-pixel chunk per iteration without LDS (nine loads, then the store): 2.2 TB/s,
+    // one memory latency per 4 KiB; row bands of four with the next item's loads in flight: 3.2 / 4.0 TB/s at batch 32 / SR 1024^2 (+10 %)
+    // but 110 instead of 92 us at batch 4 x 416 x 416, where a launch is 2.6 items per workgroup -- a loss at the reference's own batch for
+    // 0.03 % of the bench step.  Not adopted: tools/attic/edge_expand_row_band_pipeline.patch, profiles/r06_ab_edge_expand.txt.)
     __shared__ float srow[3][EDGE_MAX_W + 2];
     const int q = threadIdx.x & 7, px0 = threadIdx.x >> 3;
     f32x4 w4[9];
@@ -95,8 +100,7 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const EdgeReduceParams
             const bool ok = yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
             const float* pxp = fb + (ok ? ((long long)yy * P.W + xx) * 32 : 0);
             const f32x4 v = *reinterpret_cast<const f32x4*>(pxp + q * 4);
-            const float m = ok ? 1.f : 0.f;
-            return v * m;
+            return ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};      // a select, not a product with 0: the image's first pixel may hold a NaN / inf (0 * nan = nan)
         };
         f32x4 r0[3], r1[3], r2[3];   // rows y-1, y, y+1 at columns x-1, x, x+1
 #pragma unroll
