@@ -143,3 +143,32 @@ def test_backward_is_batch_independent_at_the_bench_batch(math):
     else:
         assert torch.equal(dx3, dx[pick])
     assert float(g3.abs().max()) <= float(g.abs().max()) * 3.0 + 1e-30
+
+
+@pytest.mark.parametrize("math", ["f16x3", "bf16x6"])
+def test_results_do_not_depend_on_the_persistent_grid(math):
+    """csrc/xsd_kernels.h: persistent_grid (round 6) picks HOW MANY workgroups walk the tiles of a conv launch from the tile count:
+    416 x 416 at batch 1 = 338 tiles -> 186 workgroups, batch 4 = 1352 -> 241, batch 8 = 2704 -> the full 256; 512 x 512 at batch 1 = 512
+    tiles -> 192 (three rounds), batch 2 = 1024 -> 256.  A tile's arithmetic must not depend on which workgroup runs it: the output and
+    dL/dx of one image are BITWISE the same at every batch size when its batch neighbours are copies of it (identical planes: identical
+    operand scales in f16x3), at the reference's tile and at BASELINE's."""
+    state = gc.make_state("dn", 32, 4, 2718)
+    m = build_module("dn", 4, 1, state).set_math(math)
+    eng = m._get_engine(torch.device("cuda", 0))
+    eng.pack(m.flat_parameters())
+    g = torch.empty_like(m.flat_parameters())
+    for T, batches in ((416, (1, 4, 8)), (512, (1, 2))):
+        x1 = _tiles((1, 1, T, T), 41).cuda()
+        dy1 = ((_tiles((1, 1, T, T), 42) - 0.5) / (T * T)).cuda()
+        ref = None
+        for B in batches:
+            x, dy = x1.expand(B, 1, T, T).contiguous(), dy1.expand(B, 1, T, T).contiguous()
+            y = eng.forward(x, save_for_backward=True).clone()
+            dx = eng.backward(dy, g, need_dx=True).clone()
+            assert torch.isfinite(y).all() and torch.isfinite(dx).all()
+            for b in range(1, B):                                   # every copy alike within the batch
+                assert torch.equal(y[b], y[0]) and torch.equal(dx[b], dx[0]), (T, B, b)
+            if ref is None:
+                ref = (y[0].clone(), dx[0].clone())
+            else:
+                assert torch.equal(y[0], ref[0]) and torch.equal(dx[0], ref[1]), (T, B)
