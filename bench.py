@@ -377,8 +377,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 32 at every N; sr_fwd: 16)")
     ap.add_argument("--tile", type=int, default=TILE,
                     help="LR tile side in pixels (default 512 = BASELINE's metric).  416 = the reference's own operating point "
-                         "(res/baseline_config.toml:13 lr_res, 832 HR); any other value is NOT the headline: the metric names the size, "
-                         "no cpu_baseline, no PMC traffic")
+                         "(res/baseline_config.toml:36 lr res, 832 HR); any other value is NOT the headline: the metric names the size, "
+                         "cpu_baseline is timed at that size, no PMC traffic")
     ap.add_argument("--math", default=os.environ.get("XSD_MATH", DEFAULT_MATH), choices=sorted(MATHS),
                     help="MFMA math mode of the conv kernels (include/xsd.h: xsd_set_math); the headline must be fp32-class")
     ap.add_argument("--input-pipeline", action="store_true",
@@ -657,8 +657,8 @@ def main():
             out.update(psnr_delta)
         if extra is not None:
             out["extra"] = extra
-        if world == 1 and not args.no_cpu_baseline and NF == 32 and T == TILE:
-            out["cpu_baseline"] = cpu_baseline(kind, train)
+        if world == 1 and not args.no_cpu_baseline and NF == 32:
+            out["cpu_baseline"] = cpu_baseline(kind, train, tile=T)      # the same step at the same tile size on the host cores (B = 1)
         print(json.dumps(out), flush=True)
     if dp:
         dist.destroy_process_group()

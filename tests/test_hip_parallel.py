@@ -166,7 +166,7 @@ def test_bench_line_reports_package_power_and_clock():
 
 def test_bench_line_at_the_reference_operating_point():
     """bench.py --tile 416 --batch 4 (res/baseline_config.toml:36; the run files' batch 4): the metric names the size, the line carries no
-    cpu_baseline and no PMC traffic (both are defined for BASELINE's 512 x 512 line), the whole-step figures scale with the pixels, the
+    PMC traffic (collected for BASELINE's 512 x 512 line only), the whole-step figures scale with the pixels, the
     unprofiled leg is there, and the persistent grid of this size is the measured rule's (1352 tiles -> 241 workgroups on 256 CUs)."""
     import ctypes
     import json
@@ -175,12 +175,12 @@ def test_bench_line_at_the_reference_operating_point():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "XSD_DIST_BACKEND", "XSD_FORCE_DP"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--tile", "416", "--batch", "4", "--steps", "6", "--warmup", "2", "--no-extra",
-                        "--no-sustained", "--no-psnr"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+                        "--no-sustained", "--no-psnr", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = p.stdout.decode(errors="replace")
     assert p.returncode == 0, out[-3000:]
     d = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert d["metric"] == "XMM 416x416 tiles/sec (train step)" and d["config"]["tile"] == "1x416x416" and d["config"]["per_gpu_batch"] == 4
-    assert "cpu_baseline" not in d and d["roofline"]["traffic"] is None and d["roofline"]["wgrad_kernel"]["traffic"] is None
+    assert d["roofline"]["traffic"] is None and d["roofline"]["wgrad_kernel"]["traffic"] is None
     assert 50 < d["value"] < 400 and abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-6
     assert d["unprofiled"]["value"] >= 0.98 * d["value"]                       # the per-launch events cost a few per cent at this batch, never the other way round
     ws = d["roofline"]["whole_step"]
