@@ -193,31 +193,27 @@ def test_product_library_reads_no_test_hook_from_the_environment():
 
 
 def test_persistent_conv_grid_rule():
-    """csrc/xsd_kernels.h: persistent_grid (round 6; the measured table is profiles/r06_ab_balanced_grid.txt).  A persistent conv launch
-    uses the full grid unless the launch is short (<= 8 rounds) AND its last round would be sparse (<= 0.35 of the CUs): then the smallest
-    grid with the same number of rounds plus a fifth of the way to the full grid (two rounds) or the midpoint of the two (three to eight); or it is two (nearly)
-    full rounds: then three quarters of the CUs.  Pure host arithmetic behind a diagnostic C-ABI entry: no device needed."""
+    """csrc/xsd_kernels.h: persistent_grid (round 6; the measured tables: profiles/r06_grid_scan.txt).  A persistent conv launch of at most 8
+    rounds uses the BALANCED grid -- the smallest one that needs no more rounds than the full grid -- and the full grid beyond.  Pure host
+    arithmetic behind a diagnostic C-ABI entry: no device needed."""
     import ctypes
     from xmm_superres_denoise.engine import _lib
     L = ctypes.CDLL(_lib.LIB_PATH)
     g = L.xsd_debug_persistent_grid
     g.argtypes = [ctypes.c_int, ctypes.c_int]
     assert g(200, 256) == 200 and g(256, 256) == 256 and g(1, 256) == 1 and g(0, 256) == 0
-    assert g(338, 256) == 186            # a 416 x 416 image (the reference's tile), batch 1: 2 rounds, tail 82 / 256 = 0.32 -> a fifth of the way from 169 x 2 to the full grid
-    assert g(1352, 256) == 241           # batch 4: 6 rounds, tail 72 / 256 = 0.28 -> midway between the balanced grid (226) and the full one
-    assert g(512, 256) == 192            # 512 x 512, batch 1: two full rounds -> three rounds on three quarters of the CUs (+8.4 % measured)
-    assert g(496, 256) == 192 and g(487, 256) == 192 and g(486, 256) == 256      # ... from a 0.9 tail up (10 * tail >= 9 * ncu)
-    assert g(1024, 256) == 256 and g(768, 256) == 256                            # three / four full rounds keep the full grid
-    assert g(676, 256) == 256            # 416 x 416, batch 2: 3 rounds, tail 164 / 256 = 0.64 -> a well-filled last round keeps the full grid
-    assert g(576, 256) == 224            # 3 rounds, tail 0.25: (192 + 256) / 2
-    assert g(2704, 256) == 256           # batch 8: 11 rounds -> full
+    assert g(338, 256) == 169            # a 416 x 416 image (the reference's tile), batch 1: 169 x 2 instead of 82 x 2 + 174 x 1
+    assert g(1352, 256) == 226           # batch 4 (the reference's training batch): 6 rounds on 226 workgroups
+    assert g(676, 256) == 226            # batch 2: 3 rounds
+    assert g(512, 256) == 256 and g(1024, 256) == 256 and g(2048, 256) == 256      # full rounds stay full (512 x 512 at batch 1 / 2 / 4)
+    assert g(576, 256) == 192
+    assert g(2704, 256) == 256           # batch 8: 11 rounds -> the full grid
     assert g(16384, 256) == 256          # the bench batch (32 x 512 x 512): 64 rounds
-    assert g(2 * 256 + 89, 256) == ((2 * 256 + 89 + 2) // 3 + 256) // 2 and g(2 * 256 + 90, 256) == 256      # the 0.35 boundary: 20 * tail <= 7 * ncu
-    assert g(256 + 89, 256) == 173 + (256 - 173) // 5 and g(256 + 90, 256) == 256                               # ... with two rounds: a fifth of the way up from the balanced grid
     for ncu in (64, 120, 256, 304):
         for nt in range(0, 12 * ncu, 7):
             G = g(nt, ncu)
             rounds = -(-nt // ncu) if nt else 0
-            three = rounds == 2 and 10 * (nt - ncu) >= 9 * ncu                           # the one case that takes a round more
-            assert G <= ncu and (nt == 0 or -(-nt // G) == rounds + (1 if three else 0)), (nt, ncu, G)       # otherwise never more rounds than the full grid needs
+            assert G <= ncu and (nt == 0 or -(-nt // G) == rounds), (nt, ncu, G)       # never more rounds than the full grid needs
+            if 1 < rounds <= 8:
+                assert G == -(-nt // rounds), (nt, ncu, G)                              # ... and no workgroup more than those rounds need
     assert g(-1, 256) == -1 and g(10, 0) == -1

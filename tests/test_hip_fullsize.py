@@ -148,8 +148,7 @@ def test_backward_is_batch_independent_at_the_bench_batch(math):
 @pytest.mark.parametrize("math", ["f16x3", "bf16x6"])
 def test_results_do_not_depend_on_the_persistent_grid(math):
     """csrc/xsd_kernels.h: persistent_grid (round 6) picks HOW MANY workgroups walk the tiles of a conv launch from the tile count:
-    416 x 416 at batch 1 = 338 tiles -> 186 workgroups, batch 4 = 1352 -> 241, batch 8 = 2704 -> the full 256; 512 x 512 at batch 1 = 512
-    tiles -> 192 (three rounds), batch 2 = 1024 -> 256.  A tile's arithmetic must not depend on which workgroup runs it: the output and
+    416 x 416 at batch 1 = 338 tiles -> 169 workgroups, batch 4 = 1352 -> 226, batch 8 = 2704 -> the full 256; 512 x 512: full rounds, 256.  A tile's arithmetic must not depend on which workgroup runs it: the output and
     dL/dx of one image are BITWISE the same at every batch size when its batch neighbours are copies of it (identical planes: identical
     operand scales in f16x3), at the reference's tile and at BASELINE's."""
     state = gc.make_state("dn", 32, 4, 2718)

@@ -167,7 +167,7 @@ def test_bench_line_reports_package_power_and_clock():
 def test_bench_line_at_the_reference_operating_point():
     """bench.py --tile 416 --batch 4 (res/baseline_config.toml:36; the run files' batch 4): the metric names the size, the line carries no
     PMC traffic (collected for BASELINE's 512 x 512 line only), the whole-step figures scale with the pixels, the
-    unprofiled leg is there, and the persistent grid of this size is the measured rule's (1352 tiles -> 241 workgroups on 256 CUs)."""
+    unprofiled leg is there, and the persistent grid of this size is the balanced one (1352 tiles -> 226 workgroups on 256 CUs)."""
     import ctypes
     import json
     root = os.path.dirname(HERE)
@@ -188,7 +188,7 @@ def test_bench_line_at_the_reference_operating_point():
     from xmm_superres_denoise.engine import _lib
     L = _lib.load()
     L.xsd_debug_persistent_grid.argtypes = [ctypes.c_int, ctypes.c_int]
-    assert L.xsd_debug_persistent_grid(4 * 26 * 13, 256) == 241 and L.xsd_debug_persistent_grid(26 * 13, 256) == 186
+    assert L.xsd_debug_persistent_grid(4 * 26 * 13, 256) == 226 and L.xsd_debug_persistent_grid(26 * 13, 256) == 169
 
 
 def test_train_driver_one_rank_over_rccl(tmp_path):

@@ -20,6 +20,11 @@ __global__ __launch_bounds__(768) void shaped_kernel(const Args a)
 {
     extern __shared__ char lds[];
     if (a.mode == 0) return;
+    if (a.mode >= 10) {                    // same-address atomics at the end of a launch: mode 10 = one per wave of 8 (the conv's MFMA waves), 11 = one per workgroup
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 63 && w >= 4 && (a.mode == 10 || w == 4)) atomicMax(reinterpret_cast<unsigned int*>(a.buf), (unsigned int)(blockIdx.x * 16 + w));
+        return;
+    }
     float s = 1.f;
     if (a.mode == 2) {                     // dependent chain: slot pointer -> value -> index
         const float* p = a.slots[blockIdx.x & 7];
@@ -80,5 +85,7 @@ int main()
     a.mode = 1; run("write: + 84.5 KiB read-modify-write per WG", n, 768, lds, a, false);
     a.mode = 2; run("chain: + 3 dependent global round trips first", n, 768, lds, a, false);
     a.mode = 1; a.words_per_wg = 4096; run("write 16 KiB per WG (4 MB per launch: L2-sized)", n, 768, lds, a, false);
+    a.mode = 10; run("empty + 8 atomicMax per WG to ONE address (2048)", n, 768, lds, a, false);
+    a.mode = 11; run("empty + 1 atomicMax per WG to ONE address (256)", n, 768, lds, a, false);
     return 0;
 }

@@ -7,6 +7,23 @@
 
 namespace xsd {
 
+// max |x| of a workgroup into a slot with ONE global atomic (round 6: same-address atomics are served one after the other at the memory
+// side -- 2,048 of them at the end of a launch cost 22 us, tools/launch_floor_probe.hip; these kernels used to issue one per WAVE of up to
+// 4,096 workgroups).  Every thread of the workgroup must call it (it holds a barrier); NaN never wins fmaxf.
+__device__ __forceinline__ void publish_block_max(float m, float* slot)
+{
+    __shared__ float wave_max[16];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = wave_max[0];
+        for (int i = 1; i < (int)((blockDim.x + 63) >> 6); ++i) t = fmaxf(t, wave_max[i]);
+        atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(t));      // non-negative floats order as unsigned integers
+    }
+}
+
 // torch.clamp propagates NaN (clamp(nan, 0, 1) = nan; +-inf go to the bounds); fminf / fmaxf alone return the non-NaN operand and
 // would turn a NaN pixel into 0.  Identical to fminf(fmaxf(v, lo), hi) for every non-NaN v (round 6: tests/test_hip_abi_errors.py).
 __device__ __forceinline__ float clamp_nan(float v, float lo, float hi) { return v != v ? v : fminf(fmaxf(v, lo), hi); }
@@ -19,6 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Thread = (pixel, 4-channel quad): 8 consecutive lanes write one pixel's 128 B, a wave writes 1 KiB contiguous.
 // Algorithmic bytes/px: 4 read + 128 written.
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int EE_STAGE = 6;      // staging loads in flight per thread: 1536 elements per batch = the three rows of a 510-pixel-wide image at once
 __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams P)
 {
     // One image row per block iteration: the three rows of s around it are staged zero-padded in LDS, the thread's 9 x 4
@@ -40,15 +58,36 @@ __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams
         const int y = row % P.H;
         const float* sb = P.s + (P.s_bs ? (long long)(row / P.H) * P.s_bs : (long long)(row - y) * P.W);
         __syncthreads();
-        for (int i = threadIdx.x; i < 3 * (P.W + 2); i += 256) {
-            const int k = i / (P.W + 2), xx = i - k * (P.W + 2) - 1, yy = y + k - 1;
-            srow[k][xx + 1] = (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) ? sb[(long long)yy * P.W + xx] : 0.f;
+        // The three input rows into LDS, EE_STAGE loads per thread IN FLIGHT at once (round 6: the loop used to be load -> wait -> LDS write
+        // per element, i.e. five memory latencies behind each other per 416-pixel row: 92 us for the 91 MB of a batch-4 x 416 x 416 plane)
+        const int n3 = 3 * (P.W + 2);
+        for (int base = 0; base < n3; base += 256 * EE_STAGE) {
+            float tmp[EE_STAGE];
+#pragma unroll
+            for (int u = 0; u < EE_STAGE; ++u) {
+                const int i = base + u * 256 + (int)threadIdx.x;
+                const int k = i / (P.W + 2), xx = i - k * (P.W + 2) - 1, yy = y + k - 1;
+                tmp[u] = (i < n3 && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) ? sb[(long long)yy * P.W + xx] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < EE_STAGE; ++u) {
+                const int i = base + u * 256 + (int)threadIdx.x;
+                const int k = i / (P.W + 2);
+                if (i < n3) srow[k][i - k * (P.W + 2)] = tmp[u];
+            }
         }
         __syncthreads();
         const long long rbase = (long long)row * P.W * 32;
+        // the per-pixel side operand (the plane this launch adds to, or the mask plane: 16 B per thread and pixel) one iteration ahead
+        const bool side = P.accumulate || (P.mask && !P.bits);
+        const float* sp = P.accumulate ? P.out : P.mask;
+        f32x4 nxt = {0.f, 0.f, 0.f, 0.f};
+        if (side && px0 < P.W) nxt = *reinterpret_cast<const f32x4*>(sp + rbase + (long long)px0 * 32 + q * 4);
         for (int x = px0; x < P.W; x += 32) {
+            const f32x4 cur = nxt;
+            if (side && x + 32 < P.W) nxt = *reinterpret_cast<const f32x4*>(sp + rbase + (long long)(x + 32) * 32 + q * 4);
             f32x4 v = b4;
-            if (P.accumulate) v += *reinterpret_cast<const f32x4*>(P.out + rbase + (long long)x * 32 + q * 4);
+            if (P.accumulate) v += cur;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) v += srow[tap / 3][x + tap % 3] * w4[tap];
             const long long o = rbase + (long long)x * 32;
@@ -57,7 +96,7 @@ __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ((m >> i) & 1u) ? v[i] : v[i] * P.mslope;
             } else if (P.mask) {
-                const f32x4 m = *reinterpret_cast<const f32x4*>(P.mask + o + q * 4);
+                const f32x4 m = P.accumulate ? *reinterpret_cast<const f32x4*>(P.mask + o + q * 4) : cur;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : v[i] * P.mslope;
             }
@@ -66,11 +105,7 @@ __global__ __launch_bounds__(256) void edge_expand_kernel(const EdgeExpandParams
             for (int i = 0; i < 4; ++i) vmax = fmaxf(vmax, fabsf(v[i]));
         }
     }
-    if (P.amax) {          // wave maximum by shuffles, one atomic per wave (non-negative floats order as unsigned integers; NaN never wins fmaxf)
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
-        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(P.amax), __float_as_uint(vmax));
-    }
+    if (P.amax) publish_block_max(vmax, P.amax);      // (P.amax is uniform: every thread arrives)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -371,13 +406,13 @@ __global__ void plane_amax_kernel(PlaneIn v, int B, int H, int W, float* slot)
         const f32x4 t = *reinterpret_cast<const f32x4*>(v.p + (long long)b * v.bs + (long long)y * v.rs + (long long)x * v.ps + q * 4);
         m = fmaxf(fmaxf(m, fmaxf(fabsf(t[0]), fabsf(t[1]))), fmaxf(fabsf(t[2]), fabsf(t[3])));
     }
-    atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(m));
+    publish_block_max(m, slot);
 }
 __global__ void buffer_amax_kernel(const float* v, long long n, float* slot)
 {
     float m = 0.f;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(v[g]));
-    atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(m));
+    publish_block_max(m, slot);
 }
 
 // math mode 4 (f16x3): fp32 fragment-order panels [panel][s2][tap][lane][8 floats] (pack_weights_s3_kernel) -> the two-term fp16
@@ -564,7 +599,8 @@ hipError_t launch_edge_expand(const EdgeExpandParams& p, hipStream_t s)
     // launches complete, which is not the plane's max |x| -- no caller combines the two, and none may
     if (p.amax && p.accumulate) return hipErrorInvalidValue;
     const long long rows = (long long)p.B * p.H;
-    hipLaunchKernelGGL(edge_expand_kernel, dim3((unsigned)(rows < 4096 ? rows : 4096)), dim3(256), 0, s, p);
+    // 768 workgroups = the resident set (three per CU at 49 KB of LDS each); every workgroup publishes one atomic when it ends
+    hipLaunchKernelGGL(edge_expand_kernel, dim3((unsigned)(rows < 768 ? rows : 768)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 hipError_t launch_edge_reduce(const EdgeReduceParams& p, hipStream_t s)
@@ -630,7 +666,7 @@ hipError_t launch_pack_weights_s3(const float* params, const PackDesc* descs_dev
 }
 hipError_t launch_plane_amax(const PlaneIn& v, int B, int H, int W, float* slot, hipStream_t s)
 {
-    hipLaunchKernelGGL(plane_amax_kernel, dim3(grid_for((long long)B * H * W * 8, 256)), dim3(256), 0, s, v, B, H, W, slot);
+    hipLaunchKernelGGL(plane_amax_kernel, dim3(grid_for((long long)B * H * W * 8, 256, 1024)), dim3(256), 0, s, v, B, H, W, slot);
     return hipGetLastError();
 }
 hipError_t launch_buffer_amax(const float* v, long long n, float* slot, hipStream_t s)

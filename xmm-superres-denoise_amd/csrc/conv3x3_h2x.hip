@@ -125,6 +125,7 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
             desc[10 + tid] = reinterpret_cast<unsigned long long>(P.wstep[tid]);
         }
         if (tid < 160) bias_lds[tid] = (P.bias && tid < 32 * n_out) ? P.bias[tid] : 0.f;
+        if (tid == 0) desc[15] = 0ull;      // the workgroup's max-|x| combiner: [31:0] running maximum (float bits), [63:32] MFMA waves arrived
     };
     static_assert(160 <= X3_LT, "the table-filling threads belong to the staging waves");
 
@@ -666,10 +667,20 @@ __device__ __forceinline__ void conv3x3_h2x_body(const ConvParams& P)
         m = dpp_max(m, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});   // row_shr:8
         m = dpp_max(m, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 -> rows 1, 3
         m = dpp_max(m, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast:31 -> rows 2, 3
+        // ONE global atomic per workgroup and plane (round 6).  Eight per workgroup -- 2,048 atomics on one address at the end of every
+        // launch -- cost 22 us per launch on this device whatever the launch computed (tools/launch_floor_probe.hip: an empty
+        // conv-shaped launch 2.6 us, with 8 atomicMax per workgroup to one address 24.5 us, with one per workgroup 4.2 us): same-address
+        // atomics are served one after the other at the memory side.  The MFMA waves combine through an LDS word (ds_max), the last
+        // one to arrive (an LDS counter; LDS operations of a wave complete in order, so its read sees every maximum) publishes.
         if (lane == 63) {
+            unsigned int* comb = reinterpret_cast<unsigned int*>(desc + 15);
+            atomicMax(&comb[0], __float_as_uint(m));                     // non-negative floats order as integers
+            if (atomicAdd(&comb[1], 1u) == (unsigned int)(X3_MWAVES - 1)) {
+                const unsigned int all = atomicMax(&comb[0], 0u);
 #pragma unroll
-            for (int j = 0; j < 5; ++j)
-                if (j < n_out && P.out[j].amax) atomicMax(reinterpret_cast<unsigned int*>(P.out[j].amax), __float_as_uint(m));   // non-negative floats order as integers
+                for (int j = 0; j < 5; ++j)
+                    if (j < n_out && P.out[j].amax) atomicMax(reinterpret_cast<unsigned int*>(P.out[j].amax), all);
+            }
         }
     }
 #ifdef XSD_DIAG

@@ -40,29 +40,20 @@ struct PerDevice {
 };
 
 // Workgroups of a persistent conv launch over `ntiles` tiles on `ncu` compute units (one workgroup per CU; workgroup b walks tiles
-// b, b + G, b + 2G, ...).  The launch lasts as long as its longest workgroup: rounds = ceil(ntiles / ncu) tiles.  With the full grid
-// the LAST round is run by the `tail` = ntiles - (rounds - 1) ncu workgroups that have one tile more than the others.  When that tail
-// is sparse, the grid is instead the smallest one that needs no more rounds -- every workgroup gets the same number of tiles and the
-// CUs that would have run one tile fewer stay dark: 338 tiles (a 416 x 416 image, the reference's tile at its default batch 1) run as
-// 169 x 2 instead of 82 x 2 + 174 x 1.  Same critical path in tiles, measured faster -- the two-tile workgroups share the L2s, the
-// fabric and the power budget with 87 fewer neighbours for the whole launch instead of running the first round in a full house.
-// Round 6, same device, alternating, DN forward (profiles/r06_ab_balanced_grid.txt: 36 cells, batch 1 - 8 x tile 384 - 480), gain of
-// "always balance" over "never" by (rounds, tail / ncu):  2 rounds: 0.12 +20.6 %, 0.27 +9.2 %, 0.32 +5.4 %, 0.48 +0.8 %, 0.53 -1.3 %,
-// 0.76 -4.1 %;  3: 0.25 +5.4 %, 0.54 -3.1 %, 0.64 -3.8 %;  4: 0.06 +9.1 %, 0.38 -1.8 %, 0.52 -3.8 %;  5: 0.43 -2.2 %, 0.59 -3.2 %;
-// 6: 0.08 +3.1 %, 0.28 +0.2 %;  7: 0.12 +1.8 %, 0.75 -1.7 %;  8: 0.03 +1.8 %, 0.62 -1.7 %;  9 - 15 rounds: -0.2 ... -1.0 % everywhere.
-// Hence the rule: balance when the tail is at most 0.35 of the CUs and the launch has at most 8 rounds; otherwise the full grid (a
-// well-filled last round is better served by 256 workgroups than by 226 -- and the bench batch, 64 rounds, never takes this path).
-// WHY (forced-grid stamps, profiles/r06_grid_scan.txt): the in-kernel clock of the batch-1 forward is 1.79 GHz with 256 workgroups
-// in flight, 1.95 with 169, 1.98 with 192, 2.22 with 128 -- off the AVERAGE power bound the chip still clocks by how many CUs run
-// matrix instructions at once, so dark CUs buy the busy ones clock.  The same scan found the one case where a THIRD round pays: two
-// (nearly) full rounds -- 512 tiles = one 512 x 512 image, or four 256 x 256 ones -- run 8.4 % / 8.5 % faster on three quarters of
-// the CUs (192 workgroups: 128 x 3 + 64 x 2 tiles; 184 - 200 within 1 %; the balanced 171 x 3: +4.2 %), 496 tiles +5.6 %; at a
-// 0.70 - 0.76 tail it is a wash (0 ... +2.7 %) and for 4 or 8 full rounds one round more loses 1.2 % / 3.4 %.
-// A third scan (near-full grids, sparse tails, 3 - 8 rounds) placed the optimum of the multi-round launches BETWEEN the balanced and
-// the full grid -- 1352 tiles (four 416 x 416 images, the reference's training batch): 226 (balanced) 491.5, 232 496.4, 240 502.5, 248 500.9,
-// 256 490.9 tiles/s; 1300: 217 -> 510.4, 232 -> 522.3, 256 -> 492.4; 1568: 224 -> 429.1, 240 -> 438.7; 1800: 225 -> 379.3, 240 -> 384.2; 576:
-// 192 -> 454, 232 -> 468.5; 1350: 225 -> 368.7, 240 -> 378.1 -- the midpoint of the two is within 0.5 % of the best in all seven (+1.3 ... +2.5 %
-// over balanced); with two rounds the optimum sits a little above the balanced grid (338 tiles: 169 -> 300, 176 - 192 -> 306, 208 -> 298).
+// b, b + G, b + 2G, ...).  The launch lasts as long as its longest workgroup: rounds = ceil(ntiles / ncu) tiles.  With the full grid the
+// last round is run by the ntiles - (rounds - 1) ncu workgroups that have one tile more than the others; the BALANCED grid is the smallest
+// one that needs no more rounds -- every workgroup gets the same number of tiles and the CUs that would have run one tile fewer stay dark:
+// 338 tiles (a 416 x 416 image, the reference's tile at its default batch 1) run as 169 x 2 instead of 82 x 2 + 174 x 1.  Same critical
+// path in tiles, measured faster, because off the average power bound the chip still clocks by how many CUs run matrix instructions at
+// once (forced-grid stamps: in-kernel clock 1.79 GHz with 256 workgroups in flight, 1.95 with 169, 2.22 with 128): dark CUs buy the busy
+// ones clock.  Scan after the one-atomic-per-workgroup fix (profiles/r06_grid_scan.txt, scan 4; DN forward, tiles/s, full -> balanced):
+// 338 tiles 369 -> 388 (+5 %), 288: 377 -> 426 (+13 %), 450: 331 -> 335, 676 (3 rounds): 470 -> 483 (+2.7 %), 576: 502 -> 526 (+4.8 %), 1352 (6
+// rounds: the reference's training batch of four): 493 -> 512 (+3.8 %), 1300: 514 -> 531; every grid between the balanced and the full one lies
+// between the two, every grid that needs a round more is far worse (512 tiles: 256 -> 306, 192 -> 276).  From 9 rounds up the two forms are
+// within +- 1 % and the full grid is kept (the bench batch, 64 rounds, never takes this path).
+// (The first three scans of the round were taken while every MFMA wave published its plane maximum with a global atomic of its own --
+// 2,048 same-address atomics, 22 us, at the end of every launch -- and a smaller grid also meant fewer atomics: they showed optima ABOVE the
+// balanced grid and a third round paying for two full ones; both were artefacts of that and went with it: docs/LAB_NOTEBOOK.md R6.14.)
 // Results are bitwise identical either way (a tile's arithmetic does not depend on which workgroup runs it).
 constexpr int BALANCED_GRID_MAX_ROUNDS = 8;
 inline int persistent_grid(int ntiles, int ncu)
@@ -77,12 +68,7 @@ inline int persistent_grid(int ntiles, int ncu)
     if ((XSD_GRID_MODE) == 2) return (ntiles + rounds) / (rounds + 1);
     return (XSD_GRID_MODE) ? balanced : ncu;
 #endif
-    const int tail = ntiles - (rounds - 1) * ncu;                       // 1 .. ncu workgroups would run the last round
-    if (rounds == 2 && 10 * tail >= 9 * ncu) return 3 * ncu / 4;        // two (nearly) full rounds: three rounds on three quarters of the CUs
-    if (rounds > BALANCED_GRID_MAX_ROUNDS || 20 * tail > 7 * ncu) return ncu;
-    // a sparse last round: a fifth of the way from the balanced grid to the full one with two rounds (338 tiles: 169 -> 300.0, 176 -> 306.1,
-    // 192 -> 306.0, 208 -> 297.9 tiles/s; 288 tiles: 144 -> 336.6, 160 -> 341.2, 169 -> 342.6, 176 -> 339.8), midway with three to eight
-    return rounds == 2 ? balanced + (ncu - balanced) / 5 : (balanced + ncu) / 2;
+    return rounds <= BALANCED_GRID_MAX_ROUNDS ? balanced : ncu;
 }
 
 constexpr int TILE_H = 8;          // output rows per workgroup
