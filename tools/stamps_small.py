@@ -22,7 +22,8 @@ m = GeneratorRRDB_DN(1, 1, 32, 4).cuda().set_math(math)
 x = torch.rand(B, 1, T, T, device='cuda')
 NCONV = 61
 tiles = B * ((T + 15) // 16) * ((T + 31) // 32)
-nwg = min(tiles, torch.cuda.get_device_properties(0).multi_processor_count)
+ncu = torch.cuda.get_device_properties(0).multi_processor_count
+nwg = min(tiles, ncu)
 if os.environ.get("XSD_EXP_GRID"):      # an experiment build with a forced grid (-DXSD_GRID_ENV): that many workgroups, no plan-time tuning
     nwg = min(tiles, int(os.environ["XSD_EXP_GRID"]))
 with torch.no_grad():
@@ -35,6 +36,9 @@ with torch.no_grad():
         for _ in range(3):
             m(x)
         torch.cuda.synchronize()
+    if not os.environ.get("XSD_EXP_GRID") and hasattr(eng.L, "xsd_debug_persistent_grid"):      # the grid the launcher really uses (csrc/xsd_kernels.h: persistent_grid)
+        eng.L.xsd_debug_persistent_grid.argtypes = [ctypes.c_int, ctypes.c_int]
+        nwg = int(eng.L.xsd_debug_persistent_grid(tiles, ncu))
     out = (ctypes.c_uint64 * 32)()
     eng.L.xsd_debug_stamps(eng.h, 1, None)
     eng.profile_enable(True)
