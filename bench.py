@@ -368,11 +368,21 @@ def self_launch(args) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def default_steps(batch, tile, train, math):
+    """K when --steps is not given: ~5 s of timed region, from the full-batch step time (255 ms for 32 x 512^2 in f16x3) scaled by the
+    work; never fewer than 20 (the bench batch's K).  A timed region of under a second starts before the package has settled at its
+    1400 W cap and flatters the line (docs/LAB_NOTEBOOK.md R6.16).  A function of the arguments only: every rank computes the same K."""
+    est_ms = 255.0 * (batch * tile * tile) / (32.0 * 512 * 512) * (1.0 if train else 0.35) * {"bf16x6": 1.55, "fp32": 2.7}.get(math, 1.0)
+    return max(20, min(5000, int(5000.0 / est_ms)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=0,
+                    help="timed steps K (default: 20 at the bench batch, more for smaller work so that the timed region is ~5 s: a region of "
+                         "under a second starts before the package has settled at its power cap and flatters the line)")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed warm-up steps W (default: max(5, K // 4))")
     ap.add_argument("--workload", default="dn_train", choices=["dn_train", "sr_train", "dn_fwd", "sr_fwd"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 32 at every N; sr_fwd: 16)")
     ap.add_argument("--tile", type=int, default=TILE,
@@ -451,6 +461,10 @@ def main():
         raise SystemExit("--tile must be in [16, 2048]")
     if args.input_pipeline and T < 411:
         raise SystemExit("--input-pipeline pads 411 x 403 count tiles: --tile must be >= 411")
+    if args.steps <= 0:
+        args.steps = default_steps(B, T, train, args.math)
+    if args.warmup < 0:
+        args.warmup = max(5, args.steps // 4)
 
     torch.manual_seed(0)  # same seeded default init on every rank (DP replicas start identical)
     NF = args.filters

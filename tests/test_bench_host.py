@@ -131,3 +131,17 @@ def test_roofline_block_edge_kernels_and_tile_size():
     assert abs(r416["whole_step"]["algorithmic_TFLOPs"] - s * w512["algorithmic_TFLOPs"]) < 1e-9
     other = bench.roofline_block("f16x3", prof, 32, "dn", True, 1, 126.0, False)           # another width: no whole-step figures, the edge block stays
     assert "whole_step" not in other and "edge" in other
+
+
+def test_default_steps_give_a_settled_timed_region():
+    """bench.default_steps (round 6, docs/LAB_NOTEBOOK.md R6.16): without --steps the bench batch runs the driver's 20 steps, smaller work
+    runs more so that the timed region stays ~5 s (a region of under a second is timed before the package settles at its power cap);
+    the count depends on the arguments only, so every rank of a multi-GPU run computes the same K."""
+    import bench
+    assert bench.default_steps(32, 512, True, "f16x3") == 20
+    assert bench.default_steps(32, 512, True, "bf16x6") == 20 and bench.default_steps(64, 512, True, "f16x3") == 20
+    k = bench.default_steps(1, 416, False, "f16x3")          # one 416 x 416 image per call: ~2.4 ms each
+    assert 1500 <= k <= 5000
+    k4 = bench.default_steps(4, 416, True, "f16x3")          # the reference's training batch of four: ~22 ms per step
+    assert 150 <= k4 <= 300 and 3.0 <= k4 * 0.0217 <= 6.5
+    assert bench.default_steps(1, 16, False, "f16x3") == 5000
