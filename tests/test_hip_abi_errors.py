@@ -200,3 +200,33 @@ def test_non_finite_input_propagates_like_the_reference(bad):
         with torch.no_grad():
             yc = m(torch.from_numpy(xc).cuda()).cpu().numpy()
         assert np.isfinite(yc).all() and np.abs(yc - oracle.forward("dn", 32, 1, oracle.flatten_state(state), xc)).max() < 1e-5, mode
+
+
+@pytest.mark.parametrize("kind", ["dn", "sr"])
+def test_empty_batch_like_torch(kind):
+    """The reference's modules are torch convs: an empty batch gives an empty output of the right shape and zero gradients (it is what a
+    rank with an empty shard sees).  The C ABI refuses B < 1 (include/xsd.h), so the module answers without a launch -- and a real batch
+    through the same module afterwards is untouched by it."""
+    import gen_common as gc
+    from util_hip import build_module
+    state = gc.make_state(kind, 32, 1, 731)
+    m = build_module(kind, 1, 1, state)
+    s = 2 if kind == "sr" else 1
+    x = torch.zeros(0, 1, 24, 40, device="cuda", requires_grad=True)
+    y = m(x)
+    assert tuple(y.shape) == (0, 1, 24 * s, 40 * s) and y.requires_grad
+    y.sum().backward()
+    assert tuple(x.grad.shape) == (0, 1, 24, 40)
+    for n, p in m.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape and not p.grad.any(), n
+    with torch.no_grad():
+        assert tuple(m(torch.zeros(0, 1, 8, 8, device="cuda")).shape) == (0, 1, 8 * s, 8 * s)
+    from xmm_superres_denoise.engine import XsdError
+    with pytest.raises(XsdError, match="x must be"):
+        m(torch.zeros(0, 2, 8, 8, device="cuda"))
+    xr = torch.from_numpy(gc.make_input((2, 1, 24, 40), 732)).cuda()
+    with torch.no_grad():
+        y1 = m(xr)
+        m(torch.zeros(0, 1, 24, 40, device="cuda"))
+        y2 = m(xr)
+    assert torch.equal(y1, y2)

@@ -63,6 +63,16 @@ def backward_recompute(eng, x, dy, grads, need_dx, chunk, last_chunk_hook=None):
     return dx
 
 
+def _split_flat(grads, plist):
+    """the flat gradient as one view per parameter (state_dict order), None where none is wanted"""
+    outs, off = [], 0
+    for p in plist:
+        n = p.numel()
+        outs.append(grads[off:off + n].view_as(p) if p.requires_grad else None)
+        off += n
+    return outs
+
+
 class _EngineFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, need, x, *params):
@@ -72,8 +82,14 @@ class _EngineFn(torch.autograd.Function):
         ctx.need_dx = x.requires_grad
         ctx.recompute = bool(need and module.memory_efficient)
         ctx.flat_version = module._flat._version
+        # torch's convs take an empty batch (empty output, zero gradients: the reference's modules do, e.g. for an empty shard);
+        # the C ABI refuses B < 1, so there is nothing to launch and the answer is made here
+        ctx.empty = x.dim() == 4 and x.shape[0] == 0 and x.shape[1] == eng.in_channels
         if need:
             ctx.save_for_backward(x)   # 1 channel: 1/2000 of the activations; lets a displaced context recompute
+        if ctx.empty:
+            ctx.generation = None
+            return x.new_empty((0, eng.out_channels, x.shape[2] * eng.scale, x.shape[3] * eng.scale))
         if ctx.recompute:
             ctx.generation = None
             return forward_chunked(eng, x.contiguous(), me_chunk())
@@ -89,6 +105,10 @@ class _EngineFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         if tuple(dy.shape) != (x.shape[0], eng.out_channels, x.shape[2] * eng.scale, x.shape[3] * eng.scale):
             raise XsdError(f"dy has shape {tuple(dy.shape)} for an input of shape {tuple(x.shape)}")
+        if ctx.empty:
+            grads.zero_()
+            dx = torch.zeros_like(x) if ctx.need_dx else None
+            return (None, None, dx, *_split_flat(grads, m._plist))
         stale = not ctx.recompute and not eng.has_saved(ctx.generation)
         if (ctx.recompute or stale) and m._flat._version != ctx.flat_version:
             # same rule as torch's saved-tensor version check: the forward must be re-run with the weights it saw
@@ -105,12 +125,7 @@ class _EngineFn(torch.autograd.Function):
             dx = eng.backward(dy.contiguous(), grads, need_dx=ctx.need_dx, generation=eng.generation)
         else:
             dx = eng.backward(dy.contiguous(), grads, need_dx=ctx.need_dx, generation=ctx.generation)
-        outs, off = [], 0
-        for p in m._plist:
-            n = p.numel()
-            outs.append(grads[off:off + n].view_as(p) if p.requires_grad else None)
-            off += n
-        return (None, None, dx, *outs)
+        return (None, None, dx, *_split_flat(grads, m._plist))
 
 
 class _GeneratorRRDB(nn.Module):
