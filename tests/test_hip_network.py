@@ -367,6 +367,72 @@ def test_two_forwards_before_backward_are_reentrant():
     assert (g - (g1 + g2)).abs().max().item() <= 1e-6 * (g1 + g2).abs().max().item()
 
 
+def test_first_forward_under_inference_mode_leaves_the_module_trainable():
+    """Lightning validates -- and sanity-checks before the first training step -- under torch.inference_mode(): the module's first
+    forward, the one that lays the parameters into the engine's flat buffer, happens there.  A buffer created in that mode would be an
+    inference tensor (no version counter, no in-place update outside the mode): the module could never be trained afterwards.  The
+    same steps with and without that first validation forward must give the same parameters."""
+    state = gc.make_state("dn", 32, 1, 741)
+    x = torch.from_numpy(gc.make_input((2, 1, 24, 40), 742)).cuda()
+    t = torch.from_numpy(gc.make_input((2, 1, 24, 40), 743)).cuda()
+
+    def run(validate_first):
+        m = build_module("dn", 1, 1, state)
+        if validate_first:
+            with torch.inference_mode():
+                yv = m(x)
+            assert yv.is_inference() and not m._flat.is_inference() and not any(p.is_inference() for p in m.parameters())
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+        for _ in range(2):
+            opt.zero_grad()
+            torch.nn.functional.l1_loss(m(x), t).backward()
+            opt.step()
+        with torch.inference_mode():
+            return m(x).clone(), torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
+
+    ya, pa = run(True)
+    yb, pb = run(False)
+    assert torch.equal(pa, pb) and torch.equal(ya, yb)
+
+
+def test_a_used_module_can_be_deep_copied_and_pickled(tmp_path):
+    """The reference's generators are plain torch modules: copy.deepcopy (EMA / SWA copies), torch.save(module) and spawn-style launchers
+    work on them at any time.  Here a module that has run holds an engine handle (a pointer of this process) and parameters that are views
+    of one flat buffer: the copy must come out as an independent, working module with the same parameters -- its own engine, its own
+    buffer -- and training the copy must not move the original."""
+    import copy
+    import pickle
+    state = gc.make_state("sr", 32, 1, 751)
+    m = build_module("sr", 1, 1, state)
+    x = torch.from_numpy(gc.make_input((2, 1, 24, 40), 752)).cuda()
+    t = torch.from_numpy(gc.make_input((2, 1, 48, 80), 753)).cuda()
+    with torch.no_grad():
+        y = m(x)
+    c = copy.deepcopy(m)
+    u = pickle.loads(pickle.dumps(m))
+    torch.save(m, tmp_path / "whole_module.pt")
+    for other in (c, u):
+        assert other._engine is None
+        with torch.no_grad():
+            assert torch.equal(other(x), y)
+        assert other._engine is not m._engine and other._flat.data_ptr() != m._flat.data_ptr()
+    before = m._flat.clone()
+    opt = torch.optim.Adam(c.parameters(), lr=1e-3)
+    torch.nn.functional.l1_loss(c(x), t).backward()
+    opt.step()
+    assert torch.equal(m._flat, before) and not torch.equal(c._flat, before)
+    with torch.no_grad():
+        assert torch.equal(m(x), y) and not torch.equal(c(x), y)
+    # the composed loss holds a handle too
+    from xmm_superres_denoise.utils.loss_functions import Loss
+    loss = Loss({"l1": 0.7, "psnr": 0.3})
+    l2 = copy.deepcopy(loss)
+    l3 = pickle.loads(pickle.dumps(loss))
+    p = y.clone().requires_grad_(True)
+    v = loss(p, t)
+    assert torch.equal(l2(p, t), v) and torch.equal(l3(p, t), v) and l2.h.value != loss.h.value
+
+
 def test_backward_rejects_mismatched_dy_and_stale_generation():
     from xmm_superres_denoise.engine import XsdError
     state = gc.make_state("dn", 32, 1, 41)

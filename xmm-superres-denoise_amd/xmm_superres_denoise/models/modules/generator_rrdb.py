@@ -168,6 +168,14 @@ class _GeneratorRRDB(nn.Module):
         self._plist = None
         self._math = None  # None: engine default (env XSD_MATH, else f16x3)
 
+    # ---- copies and pickles (copy.deepcopy for EMA / SWA copies, torch.save(module), spawn-style launchers) --------------------
+    def __getstate__(self):
+        """The engine handle belongs to this process and this module: a copy or an unpickled module builds its own (and lays its own
+        flat parameter buffer) at its first forward, exactly like a freshly constructed one."""
+        st = self.__dict__.copy()
+        st["_engine"] = st["_engine_dev"] = st["_flat"] = st["_plist"] = None
+        return st
+
     # ---- flat parameter buffer ---------------------------------------------------------------------------------
     def _num_upsample(self):
         return 1
@@ -187,13 +195,16 @@ class _GeneratorRRDB(nn.Module):
                     break
                 off += p.numel()
         if not ok:
-            flat = torch.empty(sum(p.numel() for p in plist), dtype=torch.float32, device=dev)
-            off = 0
-            for p in plist:
-                n = p.numel()
-                flat[off:off + n].copy_(p.data.reshape(-1).float())
-                p.data = flat[off:off + n].view(p.shape)
-                off += n
+            # The first forward of a Lightning run is a validation sanity check under torch.inference_mode(): a buffer made there would be
+            # an inference tensor and the parameters views of it -- no optimizer could ever update them.  Make it a normal tensor.
+            with torch.inference_mode(False):
+                flat = torch.empty(sum(p.numel() for p in plist), dtype=torch.float32, device=dev)
+                off = 0
+                for p in plist:
+                    n = p.numel()
+                    flat[off:off + n].copy_(p.data.reshape(-1).float())
+                    p.data = flat[off:off + n].view(p.shape)
+                    off += n
             self._flat = flat
         self._plist = plist
         return self._flat

@@ -138,6 +138,7 @@ class Loss:
             raise XsdError(f"unknown loss terms {sorted(unknown)}")
         self.weights = {k: float(weights.get(k, 0.0)) for k in TERMS}
         self.correction = float(correction)
+        self._ctor = dict(weights=dict(self.weights), correction=self.correction, kernel_size=kernel_size, sigma=sigma, k1=k1, k2=k2)
         self.L = load()
         cfg = _LossConfigC(*[self.weights[k] for k in TERMS], self.correction, sigma, k1, k2, kernel_size)
         h = ctypes.c_void_p()
@@ -150,6 +151,12 @@ class Loss:
         if getattr(self, "h", None) and self.h.value:
             self.L.xsd_loss_destroy(self.h)
             self.h = ctypes.c_void_p()
+
+    def __getstate__(self):      # a copy / an unpickled loss creates its own handle (the handle is a pointer of this process)
+        return dict(self._ctor)
+
+    def __setstate__(self, st):
+        self.__init__(**st)
 
     def _eval(self, preds, target, want_grad):
         _require_cuda_f32(preds, "preds")
