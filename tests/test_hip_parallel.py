@@ -266,3 +266,72 @@ def test_train_driver_two_ranks(tmp_path):
     out = p.stdout.decode(errors="replace")
     assert p.returncode == 0, out[-3000:]
     assert out.count("train/loss") == 3 and "validation:" in out and os.path.exists(ck)
+
+
+def test_torch_ddp_wrapper_around_the_module(tmp_path):
+    """train.py:141-155 of the reference: Lightning's DDP strategy wraps the LightningModule -- and with it the generator -- in
+    torch.nn.parallel.DistributedDataParallel.  What that wrapper does to a module (parameter broadcast in place at construction,
+    AccumulateGrad hooks on every parameter, gradient buckets copied back into .grad) must work on parameters that are views of the
+    engine's flat buffer and on gradients that are views of one flat gradient: a one-rank group (the collectives all execute), two Adam
+    steps, bit-equal to the bare module."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    import gen_common as gc
+    from util_hip import build_module
+    state = gc.make_state("dn", 32, 1, 761)
+    x = torch.from_numpy(gc.make_input((2, 1, 24, 40), 762)).cuda()
+    t = torch.from_numpy(gc.make_input((2, 1, 24, 40), 763)).cuda()
+
+    def run(wrap):
+        m = build_module("dn", 1, 1, state)
+        net = DistributedDataParallel(m, device_ids=[0]) if wrap else m
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+        for _ in range(2):
+            opt.zero_grad()
+            torch.nn.functional.l1_loss(net(x), t).backward()
+            opt.step()
+        flat = m.flatten_parameters()
+        assert all(p.data_ptr() >= flat.data_ptr() and p.data_ptr() < flat.data_ptr() + 4 * flat.numel() for p in m.parameters())   # still views
+        return flat.clone()
+
+    assert not dist.is_initialized()
+    dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "pg"), rank=0, world_size=1)
+    try:
+        wrapped = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(wrapped, run(False))
+
+
+def test_torch_ddp_two_ranks_matches_the_full_batch_step(tmp_path):
+    """Two ranks of torch DistributedDataParallel over the generator (tests/ddp_wrapper_worker.py; gloo with both ranks on the one card,
+    RCCL when two are visible): rank 1 starts from different parameters (DDP's construction-time broadcast must overwrite the views in
+    place), each rank steps on its half of the batch, the replicas end bit-identical and equal -- to fp32 rounding of the gradient mean --
+    to the bare module stepped on the whole batch."""
+    import gen_common as gc
+    from util_hip import build_module
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = os.path.join(tmp_path, "ddp.pt")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(HERE, "ddp_wrapper_worker.py"), out]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
+    got = torch.load(out, weights_only=True)
+    assert got["identical"] is True
+    state = gc.make_state("dn", 32, 1, 771)
+    m = build_module("dn", 1, 1, state)
+    start = m.flatten_parameters().clone().cpu()
+    x = torch.from_numpy(gc.make_input((4, 1, 24, 40), 772)).cuda()
+    t = torch.from_numpy(gc.make_input((4, 1, 24, 40), 773)).cuda()
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    for _ in range(2):
+        opt.zero_grad()
+        torch.nn.functional.l1_loss(m(x), t).backward()
+        opt.step()
+    want = m.flatten_parameters().cpu()
+    moved = (want - start).abs().max().item()
+    assert moved > 1e-4                                                   # the steps did something
+    assert (got["flat"] - want).abs().max().item() < 2e-3 * moved         # same update to rounding of the gradient mean
