@@ -230,3 +230,21 @@ def test_empty_batch_like_torch(kind):
         m(torch.zeros(0, 1, 24, 40, device="cuda"))
         y2 = m(xr)
     assert torch.equal(y1, y2)
+
+
+def test_second_differentiation_is_refused_by_name():
+    """The backward is HIP kernels, not torch ops: a gradient of a gradient (create_graph=True, e.g. a gradient penalty -- the reference has
+    none) cannot be formed.  torch must refuse (the first gradient carries no graph; where the incoming gradient itself requires grad,
+    once_differentiable names the function) instead of returning a second gradient that silently ignores the path."""
+    import gen_common as gc
+    from util_hip import build_module
+    m = build_module("dn", 1, 1, gc.make_state("dn", 32, 1, 781))
+    x = torch.rand(1, 1, 16, 32, device="cuda", requires_grad=True)
+    (g,) = torch.autograd.grad(m(x).sum(), x, create_graph=True)
+    assert g.shape == x.shape
+    with pytest.raises(RuntimeError, match="once_differentiable|does not require grad"):
+        g.sum().backward()
+    w = torch.ones(1, 1, 16, 32, device="cuda", requires_grad=True)
+    (g2,) = torch.autograd.grad((m(x) * w).sum(), x, create_graph=True)      # now the incoming gradient requires grad
+    with pytest.raises(RuntimeError, match="once_differentiable"):
+        g2.sum().backward()

@@ -13,6 +13,7 @@ import os
 
 import torch
 from torch import nn
+from torch.autograd.function import once_differentiable
 
 from xmm_superres_denoise.engine import Engine, XsdError
 
@@ -98,6 +99,7 @@ class _EngineFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable      # the backward is kernels, not torch ops: a second differentiation (create_graph=True) is refused by name
     def backward(ctx, dy):
         m = ctx.module
         eng = m._engine

@@ -12,6 +12,7 @@ from __future__ import annotations
 import ctypes
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from ..config.config import LossCfg
 from ..engine._lib import XsdError, check, load
@@ -123,6 +124,7 @@ class _LossFn(torch.autograd.Function):
         return out[0].clone()
 
     @staticmethod
+    @once_differentiable      # the backward is kernels, not torch ops: a second differentiation (create_graph=True) is refused by name
     def backward(ctx, g):
         (dy,) = ctx.saved_tensors
         return dy * g, None, None, None
