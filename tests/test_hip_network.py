@@ -433,6 +433,36 @@ def test_a_used_module_can_be_deep_copied_and_pickled(tmp_path):
     assert torch.equal(l2(p, t), v) and torch.equal(l3(p, t), v) and l2.h.value != loss.h.value
 
 
+def test_non_contiguous_tensors_and_side_streams_like_any_torch_module():
+    """torch modules take strided views and run on whatever stream is current.  A transposed input, a transposed incoming gradient and a
+    forward + backward issued on a side stream (the engine launches on torch's current stream: engine/_lib.py) give bit for bit what
+    contiguous tensors on the default stream give."""
+    state = gc.make_state("dn", 32, 1, 791)
+    m = build_module("dn", 1, 1, state).set_math("bf16x6")
+    base = torch.from_numpy(gc.make_input((2, 1, 40, 40), 792)).cuda()
+    dyb = torch.from_numpy(gc.make_input((2, 1, 40, 40), 793) - 0.5).cuda()
+
+    def run(x, dy):
+        x = x.detach().requires_grad_(True)
+        for p in m.parameters():
+            p.grad = None
+        y = m(x)
+        y.backward(dy)
+        return y.detach().clone(), x.grad.clone(), torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+
+    want = run(base.transpose(2, 3).contiguous(), dyb.transpose(2, 3).contiguous())
+    xt, dyt = base.transpose(2, 3), dyb.transpose(2, 3)
+    assert not xt.is_contiguous() and not dyt.is_contiguous()
+    got = run(xt, dyt)
+    assert all(torch.equal(a, b) for a, b in zip(want, got))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got = run(xt, dyt)
+    side.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(want, got))
+
+
 def test_backward_rejects_mismatched_dy_and_stale_generation():
     from xmm_superres_denoise.engine import XsdError
     state = gc.make_state("dn", 32, 1, 41)
