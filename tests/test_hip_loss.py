@@ -295,3 +295,49 @@ def test_model_validation_epoch_matches_oracle():
     for k, v in want_in.items():
         assert abs(logged[f"val/linear/in/{k}"] - v) <= 5e-6 * max(1.0, abs(v)), k
     assert model.in_metrics is None and model.metrics is not None      # input metrics are dropped after the first epoch
+
+
+def test_model_hooks_in_the_order_and_modes_a_lightning_fit_calls_them():
+    """A Lightning `fit` in miniature on Model (reference models/model.py:56-150, train.py:148-165 with Trainer defaults): sanity validation
+    under torch.inference_mode() BEFORE the first training step, then training steps with the optimizer of configure_optimizers, then a
+    validation epoch under inference mode again.  The sequence must run, train (the loss of the fixed batch falls) and give bit for bit the
+    logged values of the same sequence with no_grad in place of inference mode."""
+    from xmm_superres_denoise.config.config import model_cfg
+    from xmm_superres_denoise.metrics import get_metrics
+    from xmm_superres_denoise.models import Model
+    from xmm_superres_denoise.transforms import Normalize
+    from xmm_superres_denoise.utils import create_loss, load_loss_config
+    _, hr = mg.loss_inputs(2, 320, 320, 51)
+    lr = torch.from_numpy(hr.astype(np.float32)).cuda()[:, None] * 0.9
+    batch = (lr, torch.from_numpy(hr.astype(np.float32)).cuda()[:, None])
+
+    def fit(mode):
+        torch.manual_seed(3)
+        sc, cfg = load_loss_config("linear")
+        ds = Normalize(0.0022336, 0.0022336, "linear")
+        model = Model(model_cfg("rrdb_denoise", batch_size=2, residual_blocks=1), (320, 320), (320, 320), create_loss(sc, cfg),
+                      get_metrics(ds, [Normalize(0.0022336, 0.0022336, "linear")], "val"), None, None, None)
+        model.configure_model()
+        model.cuda()
+        with mode():                                   # Lightning's sanity check: the module's FIRST forward
+            model.validation_step(batch)
+            first = {k: float(v) for k, v in model.on_validation_epoch_end().items()}
+        opt = model.configure_optimizers()
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            loss = model.training_step(batch)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        model.on_validation_start()
+        with mode():
+            model.validation_step(batch)
+            last = {k: float(v) for k, v in model.on_validation_epoch_end().items()}
+        return first, losses, last
+
+    a = fit(torch.inference_mode)
+    b = fit(torch.no_grad)
+    assert a == b
+    first, losses, last = a
+    assert all(np.isfinite(v) for v in losses) and losses[-1] < losses[0] and last["val/loss"] < first["val/loss"]
