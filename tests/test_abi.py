@@ -217,3 +217,15 @@ def test_persistent_conv_grid_rule():
             if 1 < rounds <= 8:
                 assert G == -(-nt // rounds), (nt, ncu, G)                              # ... and no workgroup more than those rounds need
     assert g(-1, 256) == -1 and g(10, 0) == -1
+
+
+def test_normalize_is_picklable_like_the_reference():
+    """transforms/normalize.py:35-62 of the reference holds its stretch functions as plain functions: a Normalize can be pickled (spawned
+    DataLoader workers, deep copies of whatever holds one).  The mirror's .norm / .denorm are partials of a module-level function."""
+    import copy
+    import pickle
+    from xmm_superres_denoise.transforms import Normalize
+    n = Normalize(0.0022336, 0.0005584, "asinh")
+    for other in (pickle.loads(pickle.dumps(n)), copy.deepcopy(n)):
+        assert other.stretch_mode == "asinh" and float(other.hr_max) == float(n.hr_max)
+        assert other.norm.keywords == {"mode": "asinh", "inverse": False} and other.denorm.keywords == {"mode": "asinh", "inverse": True}

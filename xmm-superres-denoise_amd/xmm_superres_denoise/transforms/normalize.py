@@ -6,11 +6,17 @@ denormalize_image(image, max_val.expand(B)).
 """
 from __future__ import annotations
 
+import functools
+
 import torch
 
 from xmm_superres_denoise.engine import normalize as _hip_normalize
 
 _MODES = ("linear", "sqrt", "asinh", "log")
+
+
+def _stretch(x: torch.Tensor, mode: str, inverse: bool) -> torch.Tensor:
+    return _hip_normalize(x.contiguous(), 1.0, mode, inverse=inverse)
 
 
 class Normalize:
@@ -24,8 +30,9 @@ class Normalize:
         # The reference exposes the bare stretch functions as .norm/.denorm (used on [0,1] images by
         # XMMMetricCollection.update, metrics/xmm_metric_collection.py:136-143).  On [0,1] inputs the fused kernel with
         # max_val = 1 is exactly the stretch: clamp(0,1) and /1 are identities there.
-        self.norm = lambda x: _hip_normalize(x.contiguous(), 1.0, self.stretch_mode, inverse=False)
-        self.denorm = lambda x: _hip_normalize(x.contiguous(), 1.0, self.stretch_mode, inverse=True)
+        # (functools.partial of a module-level function, not a lambda: the object stays picklable like the reference's)
+        self.norm = functools.partial(_stretch, mode=self.stretch_mode, inverse=False)
+        self.denorm = functools.partial(_stretch, mode=self.stretch_mode, inverse=True)
 
     def normalize_image(self, image: torch.Tensor, max_val) -> torch.Tensor:
         mv = float(max_val)
