@@ -463,6 +463,33 @@ def test_non_contiguous_tensors_and_side_streams_like_any_torch_module():
     assert all(torch.equal(a, b) for a, b in zip(want, got))
 
 
+def test_recomputed_backward_refuses_parameters_updated_since_the_forward():
+    """torch refuses a backward whose saved tensors were modified in place since the forward.  Here that matters where the forward has to
+    be RE-RUN in the backward (memory_efficient; a context displaced by a later forward): re-running it with other weights would give a
+    gradient of a different function, silently.  An optimizer step updates the parameters, not the flat buffer they are views of -- and
+    their version counters are their own -- so the guard has to watch both."""
+    from xmm_superres_denoise.engine import XsdError
+    from xmm_superres_denoise.models import GeneratorRRDB_DN
+    state = gc.make_state("dn", 32, 1, 801)
+    m = GeneratorRRDB_DN(1, 1, 32, 1, memory_efficient=True)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
+    m.cuda()
+    x = torch.from_numpy(gc.make_input((2, 1, 24, 40), 802)).cuda()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    loss = m(x).sum()
+    loss.backward()                                   # untouched parameters: fine
+    opt.step()
+    loss = m(x).sum()
+    opt.step()                                        # parameters change between this forward and its (recomputing) backward
+    with pytest.raises(XsdError, match="modified in place"):
+        loss.backward()
+    loss = m(x).sum()
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()})
+    with pytest.raises(XsdError, match="modified in place"):
+        loss.backward()
+    m(x).sum().backward()                             # and the module is fine afterwards
+
+
 def test_backward_rejects_mismatched_dy_and_stale_generation():
     from xmm_superres_denoise.engine import XsdError
     state = gc.make_state("dn", 32, 1, 41)

@@ -82,7 +82,7 @@ class _EngineFn(torch.autograd.Function):
         ctx.module = module
         ctx.need_dx = x.requires_grad
         ctx.recompute = bool(need and module.memory_efficient)
-        ctx.flat_version = module._flat._version
+        ctx.flat_version = module._param_version()
         # torch's convs take an empty batch (empty output, zero gradients: the reference's modules do, e.g. for an empty shard);
         # the C ABI refuses B < 1, so there is nothing to launch and the answer is made here
         ctx.empty = x.dim() == 4 and x.shape[0] == 0 and x.shape[1] == eng.in_channels
@@ -112,7 +112,7 @@ class _EngineFn(torch.autograd.Function):
             dx = torch.zeros_like(x) if ctx.need_dx else None
             return (None, None, dx, *_split_flat(grads, m._plist))
         stale = not ctx.recompute and not eng.has_saved(ctx.generation)
-        if (ctx.recompute or stale) and m._flat._version != ctx.flat_version:
+        if (ctx.recompute or stale) and m._param_version() != ctx.flat_version:
             # same rule as torch's saved-tensor version check: the forward must be re-run with the weights it saw
             raise XsdError("parameters were modified in place between forward and backward of a pass whose activations "
                            "have to be recomputed (memory_efficient, or a later forward displaced them)")
@@ -213,6 +213,12 @@ class _GeneratorRRDB(nn.Module):
 
     def flat_parameters(self) -> torch.Tensor:
         return self.flatten_parameters()
+
+    def _param_version(self) -> int:
+        """Changes with every in-place update torch knows of: the parameters keep their OWN version counters when their .data is
+        pointed into the flat buffer (an optimizer step or load_state_dict bumps the parameter's, an update of the flat buffer itself
+        -- the fused Adam of parallel.py goes through a raw pointer and is sequenced by its caller -- the buffer's)."""
+        return self._flat._version + sum(p._version for p in self._plist)
 
     def set_math(self, mode: str):
         """Math mode of the conv kernels (Engine.set_math): 'fp32' (exact), 'bf16x6' (strict split), 'f16x3' (default split)."""
