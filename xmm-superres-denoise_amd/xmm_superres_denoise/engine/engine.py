@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes
+import functools
 
 import torch
 
@@ -24,6 +25,25 @@ def _require_cuda_f32(t: torch.Tensor, name: str):
         raise XsdError(f"{name} must be contiguous")
 
 
+def _on_engine_device(fn):
+    @functools.wraps(fn)
+    def guarded(self, *a, **k):
+        with torch.cuda.device(self.device_index):
+            return fn(self, *a, **k)
+    return guarded
+
+
+def _on_tensor_device(fn):
+    """the stateless entry points launch on the current stream of their first tensor's device: make that device current for the call"""
+    @functools.wraps(fn)
+    def guarded(t, *a, **k):
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            with torch.cuda.device(t.device):
+                return fn(t, *a, **k)
+        return fn(t, *a, **k)       # (the argument checks of fn say what is wrong with it)
+    return guarded
+
+
 class Engine:
     """One engine per model instance per GPU (xsd_create / xsd_destroy)."""
 
@@ -36,6 +56,10 @@ class Engine:
         h = ctypes.c_void_p()
         check(self.L.xsd_create(ctypes.byref(cfg), ctypes.byref(h)))
         self.h = h
+        # The C engine allocates and launches on the CURRENT device (it never switches devices itself): every call below runs under a
+        # guard for the device the engine was created on, so a process that holds modules on several GPUs, or whose current device is
+        # not the module's, still puts workspace and kernels where the tensors are (one process per GPU -- the normal case -- pays a no-op)
+        self.device_index = torch.cuda.current_device()
         self.kind = kind
         self.in_channels, self.out_channels = int(in_channels), int(out_channels)
         self.scale = 2 ** num_upsample if kind == "sr" else 1
@@ -59,6 +83,7 @@ class Engine:
 
     MATH = {"fp32": 0, "bf16x6": 3, "f16x3": 4}
 
+    @_on_engine_device
     def set_math(self, mode: str):
         """'fp32' (exact fp32 MFMA), 'bf16x6' (strict: exact 3-term bf16 split, 6 products, single-rounding MFMA accumulation)
         or 'f16x3' (default: 2-term fp16 split of power-of-two-scaled operands, 22-23 significant bits per operand, 3
@@ -71,6 +96,7 @@ class Engine:
         return {v: k for k, v in self.MATH.items()}[int(self.L.xsd_get_math(self.h))]
 
     # ---- weights
+    @_on_engine_device
     def pack(self, flat_params: torch.Tensor):
         _require_cuda_f32(flat_params, "flat_params")
         if flat_params.numel() != self.nparams:
@@ -79,6 +105,7 @@ class Engine:
         check(self.L.xsd_pack_weights(self.h, flat_params.data_ptr(), _stream_ptr(flat_params.device)))
 
     # ---- forward / backward
+    @_on_engine_device
     def forward(self, x: torch.Tensor, save_for_backward: bool = False) -> torch.Tensor:
         _require_cuda_f32(x, "x")
         if x.dim() != 4 or x.shape[1] != self.in_channels:
@@ -117,6 +144,7 @@ class Engine:
             if tuple(dx.shape) != tuple(self._x_ref.shape):
                 raise XsdError(f"dx has shape {tuple(dx.shape)}, the saved input has {tuple(self._x_ref.shape)}")
 
+    @_on_engine_device
     def backward(self, dy: torch.Tensor, flat_grads: torch.Tensor, need_dx: bool = False, generation: int | None = None):
         self._check_backward_args(dy, flat_grads, None, generation)
         dx = torch.empty_like(self._x_ref) if need_dx else None
@@ -124,6 +152,7 @@ class Engine:
                                   _stream_ptr(dy.device)))
         return dx
 
+    @_on_engine_device
     def backward_stage(self, stage: int, dy: torch.Tensor, flat_grads: torch.Tensor, dx: torch.Tensor | None = None,
                        generation: int | None = None):
         self._check_backward_args(dy, flat_grads, dx, generation)
@@ -136,6 +165,7 @@ class Engine:
         return off.value, cnt.value
 
     # ---- loss / optimizer
+    @_on_engine_device
     def l1_loss(self, y: torch.Tensor, target: torch.Tensor, want_grad: bool = True):
         _require_cuda_f32(y, "y")
         _require_cuda_f32(target, "target")
@@ -147,6 +177,7 @@ class Engine:
                                  loss.data_ptr(), y.numel(), _stream_ptr(y.device)))
         return loss, dy
 
+    @_on_engine_device
     def adam_step(self, params, grads, m, v, step, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
         for n, t in (("params", params), ("grads", grads), ("m", m), ("v", v)):
             _require_cuda_f32(t, n)
@@ -155,14 +186,17 @@ class Engine:
                                    _stream_ptr(params.device)))
 
     # ---- measurement
+    @_on_engine_device
     def profile_enable(self, on: bool):
         check(self.L.xsd_profile_enable(self.h, int(on)))
 
+    @_on_engine_device
     def profile_read(self, klass: int):
         ms, n, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
         check(self.L.xsd_profile_read(self.h, klass, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by)))
         return {"ms": ms.value, "launches": n.value, "flop": fl.value, "bytes": by.value}
 
+    @_on_engine_device
     def probe_mfma_stream(self, fmt: str = "f16", seconds: float = 2.0):
         """dense 16-bit MFMA TFLOP/s and in-kernel clock the current device sustains on the conv's bare MFMA-wave stream
         (include/xsd.h: xsd_probe_mfma_stream); blocks for about `seconds`"""
@@ -173,6 +207,7 @@ class Engine:
 
 
 # ---- stateless transform entry points --------------------------------------------------------------------------
+@_on_tensor_device
 def mask_pad_normalize(counts: torch.Tensor, mask: torch.Tensor | None, res: int, max_val: float | None,
                        stretch: str = "linear") -> torch.Tensor:
     """counts [B,Hin,Win] int32|float32 (CUDA), mask [Hin,Win] uint8 -> [B,1,res,res] float32."""
@@ -192,6 +227,7 @@ def mask_pad_normalize(counts: torch.Tensor, mask: torch.Tensor | None, res: int
     return out
 
 
+@_on_tensor_device
 def compose_input(img: torch.Tensor, agn: torch.Tensor | None, bkg: torch.Tensor | None, mask: torch.Tensor | None,
                   res: int, max_val: float | None, stretch: str = "linear", upsample: int = 1,
                   big_endian: bool = False) -> torch.Tensor:
@@ -217,6 +253,7 @@ def compose_input(img: torch.Tensor, agn: torch.Tensor | None, bkg: torch.Tensor
     return out
 
 
+@_on_tensor_device
 def normalize(img: torch.Tensor, max_val: float, stretch: str, inverse: bool = False) -> torch.Tensor:
     L = _lib.load()
     _require_cuda_f32(img, "img")
@@ -226,6 +263,7 @@ def normalize(img: torch.Tensor, max_val: float, stretch: str, inverse: bool = F
     return out
 
 
+@_on_tensor_device
 def image_upsample(x: torch.Tensor, scale: int) -> torch.Tensor:
     L = _lib.load()
     _require_cuda_f32(x, "x")

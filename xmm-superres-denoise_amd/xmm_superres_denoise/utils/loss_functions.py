@@ -161,6 +161,12 @@ class Loss:
         self.__init__(**st)
 
     def _eval(self, preds, target, want_grad):
+        if isinstance(preds, torch.Tensor) and preds.is_cuda:      # the C side allocates its workspace and launches on the current device
+            with torch.cuda.device(preds.device):
+                return self._eval_on_device(preds, target, want_grad)
+        return self._eval_on_device(preds, target, want_grad)
+
+    def _eval_on_device(self, preds, target, want_grad):
         _require_cuda_f32(preds, "preds")
         _require_cuda_f32(target, "target")
         if preds.shape != target.shape:
